@@ -1,0 +1,24 @@
+# Builds libwindtunnel.so (HIP, gfx950) in-tree and the C oracle (test infrastructure).
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+PKG       = airfoil-cfd-tool_amd
+CSRC      = $(PKG)/csrc
+LIB       = $(PKG)/lib/libwindtunnel.so
+# -ffp-contract=off: one rounding per operation, as the oracle (and the parity tests) assume.
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function
+LDFLAGS  ?= -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+
+all: lib oracle
+
+lib: $(LIB)
+
+$(LIB): $(CSRC)/windtunnel.hip $(CSRC)/kernels.hpp $(CSRC)/step_fast.hpp $(CSRC)/d2q9.hpp include/windtunnel.h
+	mkdir -p $(PKG)/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/windtunnel.hip $(LDFLAGS)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(PKG)/lib oracle/_build
+.PHONY: all lib oracle clean

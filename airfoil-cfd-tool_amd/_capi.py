@@ -1,0 +1,234 @@
+"""ctypes binding of libwindtunnel.so (include/windtunnel.h).
+
+The product path: there is no CPU fallback.  If the shared library is missing or
+cannot be loaded this module raises; if no HIP device is usable ``wt_create``
+fails and :class:`WTError` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libwindtunnel.so")
+
+WT_OK = 0
+WT_F32, WT_F64 = 0, 1
+WT_FIELD_SPEED, WT_FIELD_CP, WT_FIELD_VORT = 0, 1, 2
+WT_COMM_ID_BYTES = 128
+
+EXPORTS = (
+    "wt_create", "wt_create_slab", "wt_destroy", "wt_get_info", "wt_last_error", "wt_version",
+    "wt_comm_unique_id", "wt_comm_init_rank", "wt_link_local", "wt_step_group",
+    "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_read_f", "wt_write_f",
+    "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_field", "wt_render_rgba", "wt_sync",
+)
+
+
+class WTError(RuntimeError):
+    """A libwindtunnel call returned a negative status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libwindtunnel error {code}: {message}")
+        self.code = code
+
+
+class WtInfo(ctypes.Structure):
+    _fields_ = [("nx_global", c_int32), ("ny", c_int32), ("dtype", c_int32), ("device", c_int32),
+                ("rank", c_int32), ("nranks", c_int32), ("x0", c_int32), ("width", c_int32),
+                ("halo", c_int32), ("reserved", c_int32), ("steps_done", c_int64), ("device_bytes", c_int64)]
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """Load libwindtunnel.so.  PyTorch ships its own HIP runtime and RCCL; when
+    torch is importable it is imported FIRST so that this library binds to the
+    same libamdhip64/librccl instances (two HIP runtimes in one process do not
+    work)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `make lib` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback for the wind-tunnel kernels.")
+    try:
+        import torch  # noqa: F401  (side effect: loads torch's libamdhip64 / librccl first)
+    except Exception:  # pragma: no cover - torch is optional for single-GPU use
+        pass
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    H = c_void_p
+    sig = {
+        "wt_create": ([c_int, c_int, c_int, c_int, POINTER(H)], c_int),
+        "wt_create_slab": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(H)], c_int),
+        "wt_destroy": ([H], c_int),
+        "wt_get_info": ([H, POINTER(WtInfo)], c_int),
+        "wt_last_error": ([], c_char_p),
+        "wt_version": ([], c_char_p),
+        "wt_comm_unique_id": ([c_void_p], c_int),
+        "wt_comm_init_rank": ([H, c_void_p], c_int),
+        "wt_link_local": ([POINTER(H), c_int], c_int),
+        "wt_step_group": ([POINTER(H), c_int, c_int, c_double, c_double], c_int),
+        "wt_set_mask": ([H, c_void_p], c_int),
+        "wt_init_equilibrium": ([H, c_double], c_int),
+        "wt_step": ([H, c_int, c_double, c_double], c_int),
+        "wt_step_timed": ([H, c_int, c_double, c_double, POINTER(c_float)], c_int),
+        "wt_read_f": ([H, c_void_p], c_int),
+        "wt_write_f": ([H, c_void_p], c_int),
+        "wt_read_macro": ([H, c_void_p, c_void_p, c_void_p], c_int),
+        "wt_reduce_ranges": ([H, c_double, POINTER(c_double), POINTER(c_double), POINTER(c_double)], c_int),
+        "wt_forces": ([H, POINTER(c_double), POINTER(c_double), POINTER(c_int64), POINTER(c_int64)], c_int),
+        "wt_field": ([H, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p], c_int),
+        "wt_render_rgba": ([H, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p], c_int),
+        "wt_sync": ([H], c_int),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != WT_OK:
+        raise WTError(rc, load_library().wt_last_error().decode("utf-8", "replace"))
+
+
+def _np_dtype(dtype) -> np.dtype:
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError("dtype must be float32 or float64")
+    return dt
+
+
+class Engine:
+    """One libwindtunnel handle (a whole lattice, or one column slab of it)."""
+
+    def __init__(self, nx: int, ny: int, dtype="float32", device: int = 0,
+                 rank: int = 0, nranks: int = 1, halo: int = 0):
+        self._lib = load_library()
+        self.dtype = _np_dtype(dtype)
+        self._h = c_void_p()
+        code = WT_F32 if self.dtype == np.float32 else WT_F64
+        if nranks == 1:
+            _check(self._lib.wt_create(nx, ny, code, device, byref(self._h)))
+        else:
+            _check(self._lib.wt_create_slab(nx, ny, code, device, rank, nranks, halo, byref(self._h)))
+        info = self.info()
+        self.nx_global, self.ny = info.nx_global, info.ny
+        self.x0, self.width = info.x0, info.width
+        self.rank, self.nranks, self.halo = info.rank, info.nranks, info.halo
+
+    # -- life cycle --
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.wt_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def info(self) -> WtInfo:
+        info = WtInfo()
+        _check(self._lib.wt_get_info(self._h, byref(info)))
+        return info
+
+    # -- transports --
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(WT_COMM_ID_BYTES)
+        _check(load_library().wt_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rank(self, comm_id: bytes) -> None:
+        if len(comm_id) != WT_COMM_ID_BYTES:
+            raise ValueError("comm id must be WT_COMM_ID_BYTES long")
+        buf = ctypes.create_string_buffer(comm_id, WT_COMM_ID_BYTES)
+        _check(self._lib.wt_comm_init_rank(self._h, buf))
+
+    @staticmethod
+    def link_local(engines) -> None:
+        arr = (c_void_p * len(engines))(*[e._h for e in engines])
+        _check(load_library().wt_link_local(arr, len(engines)))
+
+    @staticmethod
+    def step_group(engines, nsteps: int, tau: float, u0: float) -> None:
+        arr = (c_void_p * len(engines))(*[e._h for e in engines])
+        _check(load_library().wt_step_group(arr, len(engines), int(nsteps), float(tau), float(u0)))
+
+    # -- state --
+    def set_mask(self, mask: np.ndarray) -> None:
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if m.shape != (self.ny, self.nx_global):
+            raise ValueError(f"mask must have shape [NY][NX] = {(self.ny, self.nx_global)}, got {m.shape}")
+        _check(self._lib.wt_set_mask(self._h, m.ctypes.data_as(c_void_p)))
+
+    def init_equilibrium(self, u0: float) -> None:
+        _check(self._lib.wt_init_equilibrium(self._h, float(u0)))
+
+    def step(self, nsteps: int, tau: float, u0: float) -> None:
+        _check(self._lib.wt_step(self._h, int(nsteps), float(tau), float(u0)))
+
+    def step_timed(self, nsteps: int, tau: float, u0: float) -> float:
+        ms = c_float()
+        _check(self._lib.wt_step_timed(self._h, int(nsteps), float(tau), float(u0), byref(ms)))
+        return float(ms.value)
+
+    def read_f(self) -> np.ndarray:
+        f = np.empty((9, self.ny, self.width), dtype=self.dtype)
+        _check(self._lib.wt_read_f(self._h, f.ctypes.data_as(c_void_p)))
+        return f
+
+    def write_f(self, f: np.ndarray) -> None:
+        a = np.ascontiguousarray(f, dtype=self.dtype)
+        if a.shape != (9, self.ny, self.width):
+            raise ValueError(f"f must have shape {(9, self.ny, self.width)}, got {a.shape}")
+        _check(self._lib.wt_write_f(self._h, a.ctypes.data_as(c_void_p)))
+
+    # -- read-backs --
+    def read_macro(self):
+        shape = (self.ny, self.width)
+        rho, ux, uy = (np.empty(shape, dtype=self.dtype) for _ in range(3))
+        _check(self._lib.wt_read_macro(self._h, rho.ctypes.data_as(c_void_p), ux.ctypes.data_as(c_void_p),
+                                       uy.ctypes.data_as(c_void_p)))
+        return rho, ux, uy
+
+    def reduce_ranges(self, u0: float):
+        a, b, c = c_double(), c_double(), c_double()
+        _check(self._lib.wt_reduce_ranges(self._h, float(u0), byref(a), byref(b), byref(c)))
+        return a.value, b.value, c.value
+
+    def forces(self):
+        fx, fy, surf, rev = c_double(), c_double(), c_int64(), c_int64()
+        _check(self._lib.wt_forces(self._h, byref(fx), byref(fy), byref(surf), byref(rev)))
+        return fx.value, fy.value, surf.value, rev.value
+
+    def field(self, mode: int, u0: float, max_s: float, cp_min: float, cp_max: float, vort_scale: float) -> np.ndarray:
+        out = np.empty((self.ny, self.width), dtype=self.dtype)
+        _check(self._lib.wt_field(self._h, int(mode), float(u0), float(max_s), float(cp_min), float(cp_max),
+                                  float(vort_scale), out.ctypes.data_as(c_void_p)))
+        return out
+
+    def render_rgba(self, mode: int, u0: float, max_s: float, cp_min: float, cp_max: float, vort_scale: float) -> np.ndarray:
+        out = np.empty((self.ny, self.width, 4), dtype=np.uint8)
+        _check(self._lib.wt_render_rgba(self._h, int(mode), float(u0), float(max_s), float(cp_min), float(cp_max),
+                                        float(vort_scale), out.ctypes.data_as(c_void_p)))
+        return out
+
+    def sync(self) -> None:
+        _check(self._lib.wt_sync(self._h))

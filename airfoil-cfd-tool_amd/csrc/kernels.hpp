@@ -1,0 +1,298 @@
+// kernels.hpp — HIP kernels of libwindtunnel.so (gfx950 / MI355X).
+//
+// DEVICE LAYOUT ("column-major SoA").  The lattice is stored with y (iy, here
+// `j`) as the FAST axis and x (ix, here `i`, the streamwise direction) as the
+// slow axis:  f[k][i][j], one plane per population k, `pitch` elements per
+// column (pitch >= NY, a multiple of 256), one pad column before column 0 and
+// one after the last column of every plane.  Why: the tunnel is sharded over
+// GPUs as COLUMN slabs, so with y fastest a ghost column is one contiguous run
+// of NY elements per population — RCCL send/recv operate straight on the
+// lattice (no pack/unpack kernels) and the slab-edge strips are ordinary
+// coalesced launches of the same kernel.  Inlet and outlet columns become whole
+// memory rows (wave-uniform branches).  Host-side arrays keep the reference's
+// [NY][NX] layout; transposition happens in the read-back/upload kernels below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "d2q9.hpp"
+
+namespace wt {
+
+struct Geom {
+    int nxl;        // local columns (ghosts included)
+    int ny;         // rows
+    int gi0;        // global column index of local column 0
+    int nx_g;       // global columns
+    long pitch;     // elements per column
+    long plane;     // elements per population plane = (nxl+2)*pitch
+};
+
+// tile classes (one per wave-tile of TILE_J consecutive j in one column), built by k_classify
+enum : uint8_t { TILE_GENERAL = 0, TILE_FAST = 1, TILE_SOLID = 2, TILE_INLET = 3, TILE_OUTLET = 4 };
+
+// --------------------------------------------------------------------------------------
+// k_step_general: one thread per lattice site, every branch of STEP_FS main()
+// (html:283-360) taken per lane.  Correct for any site; used for tiles that touch the
+// body or when vector paths do not apply.
+// --------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void site_general(const T *__restrict__ s, T *__restrict__ d, T *__restrict__ macro,
+                                             const uint8_t *__restrict__ m, const Geom &g, int i, int j,
+                                             T tau, T U0, bool emit)
+{
+    const long c = (long)i * g.pitch + j;
+    const int gi = i + g.gi0;
+    T out[9], rho, ux, uy;
+    if (m[c]) {                                                    // html:287-294 solid
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = s[opp_of(k) * g.plane + c];
+        rho = T(1.0); ux = T(0.0); uy = T(0.0);
+    } else if (gi == g.nx_g - 1) {                                 // html:301-312 outlet
+        T q[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) q[k] = s[k * g.plane + c - g.pitch];
+        rho = q[0] + q[1] + q[2] + q[3] + q[4] + q[5] + q[6] + q[7] + q[8];
+        ux = (q[1] + q[5] + q[8] - q[3] - q[6] - q[7]) / rho;
+        uy = (q[2] + q[5] + q[6] - q[4] - q[7] - q[8]) / rho;
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = q[k];
+    } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
+        rho = T(1.0); ux = U0; uy = T(0.0);
+        feq_all(rho, ux, uy, out);
+    } else {                                                       // html:324-359 interior fluid
+        T fin[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
+            fin[k] = m[src] ? s[opp_of(k) * g.plane + c] : s[k * g.plane + src];
+        }
+        collide(fin, tau, out, rho, ux, uy);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) d[k * g.plane + c] = out[k];
+    if (emit) {
+        const long mp = (long)g.nxl * g.pitch;
+        macro[c] = rho; macro[mp + c] = ux; macro[2 * mp + c] = uy;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_step_general(const T *__restrict__ fs, T *__restrict__ fd,
+                                                      T *__restrict__ macro, const uint8_t *__restrict__ mask,
+                                                      Geom g, int i_begin, int i_end, T tau, T U0, int emit)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= g.ny) return;
+    const T *s = fs + g.pitch;            // skip the pad column
+    T *d = fd + g.pitch;
+    const uint8_t *m = mask + g.pitch;
+    for (int i = i_begin + blockIdx.y; i < i_end; i += gridDim.y)
+        site_general<T>(s, d, macro, m, g, i, j, tau, U0, emit != 0);
+}
+
+// --------------------------------------------------------------------------------------
+// init: equilibriumInitData (html:474-490).  v[k] are evaluated on the host in double.
+// --------------------------------------------------------------------------------------
+template <typename T>
+struct Init9 { T v[9]; T u0; };
+
+template <typename T>
+__global__ void k_fill_equilibrium(T *__restrict__ f0, T *__restrict__ f1, T *__restrict__ macro,
+                                   Geom g, Init9<T> iv)
+{
+    const long n = g.plane;
+    const long mp = (long)g.nxl * g.pitch;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) { f0[k * n + t] = iv.v[k]; f1[k * n + t] = iv.v[k]; }
+        if (t < mp) { macro[t] = T(1.0); macro[mp + t] = iv.u0; macro[2 * mp + t] = T(0.0); }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// layout converters between the host's [NY][W] rows and the device's [i][j] columns
+// --------------------------------------------------------------------------------------
+// dst[j*W + x] = src[(i0+x)*pitch + j]   (device columns -> host rows), x in [0,W)
+template <typename T>
+__global__ void k_cols_to_rows(const T *__restrict__ src, T *__restrict__ dst, int i0, int W, int ny, long pitch)
+{
+    __shared__ T tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx: j block, by: x block
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int x = by + r, j = bx + threadIdx.x;
+        if (x < W && j < ny) tile[r][threadIdx.x] = src[(long)(i0 + x) * pitch + j];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int j = bx + r, x = by + threadIdx.x;
+        if (x < W && j < ny) dst[(long)j * W + x] = tile[threadIdx.x][r];
+    }
+}
+
+// dst[(i0+x)*pitch + j] = src[j*ld + x]  (host rows -> device columns), x in [0,W)
+template <typename T>
+__global__ void k_rows_to_cols(const T *__restrict__ src, T *__restrict__ dst, int i0, int W, int ny, long pitch, long ld)
+{
+    __shared__ T tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx: x block, by: j block
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int j = by + r, x = bx + threadIdx.x;
+        if (x < W && j < ny) tile[r][threadIdx.x] = src[(long)j * ld + x];
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int x = bx + r, j = by + threadIdx.x;
+        if (x < W && j < ny) dst[(long)(i0 + x) * pitch + j] = tile[threadIdx.x][r];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// reductions (on demand, never inside the step loop)
+// --------------------------------------------------------------------------------------
+struct RangePartial { double max_s, cp_min, cp_max; };
+struct ForcePartial { double fx, fy; long long surf, rev; };
+
+__device__ __forceinline__ double wave_max(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ double wave_min(double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ double wave_sum(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ long long wave_sum(long long v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+
+// updateFieldsFromMacro's scan (html:596-614), doubles, fluid sites of owned columns
+template <typename T>
+__global__ __launch_bounds__(256) void k_ranges(const T *__restrict__ macro, const uint8_t *__restrict__ mask, Geom g,
+                                                int i_own0, int W, double u0, RangePartial *__restrict__ part)
+{
+    const uint8_t *m = mask + g.pitch;
+    const long mp = (long)g.nxl * g.pitch;
+    double mx = 0.0, cmin = __builtin_inf(), cmax = -__builtin_inf();
+    const double cpden = 1.5 * u0 * u0;
+    const long total = (long)W * g.ny;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int x = (int)(t / g.ny), j = (int)(t % g.ny);
+        const long c = (long)(i_own0 + x) * g.pitch + j;
+        if (m[c]) continue;
+        const double rho = (double)macro[c], ux = (double)macro[mp + c], uy = (double)macro[2 * mp + c];
+        const double u = ux / u0, v = uy / u0;
+        const double cp = (rho - 1.0) / cpden;
+        const double s = hypot(u, v);
+        if (s > mx && s < 4.0) mx = s;
+        if (cp > -4.0 && cp < 1.2) { if (cp < cmin) cmin = cp; if (cp > cmax) cmax = cp; }
+    }
+    __shared__ double sh[3][4];
+    mx = wave_max(mx); cmin = wave_min(cmin); cmax = wave_max(cmax);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = mx; sh[1][w] = cmin; sh[2][w] = cmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        RangePartial r;
+        r.max_s = fmax(fmax(sh[0][0], sh[0][1]), fmax(sh[0][2], sh[0][3]));
+        r.cp_min = fmin(fmin(sh[1][0], sh[1][1]), fmin(sh[1][2], sh[1][3]));
+        r.cp_max = fmax(fmax(sh[2][0], sh[2][1]), fmax(sh[2][2], sh[2][3]));
+        part[blockIdx.x] = r;
+    }
+}
+
+// computeForces (html:650-698) seen from the fluid side: every owned fluid cell adds, for each
+// of its 4 face neighbours that is inside the grid and solid, p = rho/3 along the unit vector
+// from the fluid cell into the solid.
+template <typename T>
+__global__ __launch_bounds__(256) void k_forces(const T *__restrict__ macro, const uint8_t *__restrict__ mask, Geom g,
+                                                int i_own0, int W, ForcePartial *__restrict__ part)
+{
+    const uint8_t *m = mask + g.pitch;
+    const long mp = (long)g.nxl * g.pitch;
+    double fx = 0.0, fy = 0.0;
+    long long surf = 0, rev = 0;
+    const long total = (long)W * g.ny;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int x = (int)(t / g.ny), j = (int)(t % g.ny);
+        const int i = i_own0 + x;
+        const int gi = i + g.gi0;
+        const long c = (long)i * g.pitch + j;
+        if (m[c]) continue;
+        // solid neighbour at (gi+dx, j+dy) inside the grid
+        const int sxp = (gi + 1 < g.nx_g) && m[c + g.pitch];
+        const int sxm = (gi - 1 >= 0) && m[c - g.pitch];
+        const int syp = (j + 1 < g.ny) && m[c + 1];
+        const int sym = (j - 1 >= 0) && m[c - 1];
+        const int nf = sxp + sxm + syp + sym;
+        if (nf == 0) continue;
+        const double p = (double)macro[c] / 3.0;
+        fx += p * (double)(sxp - sxm);
+        fy += p * (double)(syp - sym);
+        surf += nf;
+        if (macro[mp + c] < T(0.0)) rev += nf;
+    }
+    __shared__ double shd[2][4];
+    __shared__ long long shl[2][4];
+    fx = wave_sum(fx); fy = wave_sum(fy); surf = wave_sum(surf); rev = wave_sum(rev);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { shd[0][w] = fx; shd[1][w] = fy; shl[0][w] = surf; shl[1][w] = rev; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ForcePartial r;
+        r.fx = shd[0][0] + shd[0][1] + shd[0][2] + shd[0][3];
+        r.fy = shd[1][0] + shd[1][1] + shd[1][2] + shd[1][3];
+        r.surf = shl[0][0] + shl[0][1] + shl[0][2] + shl[0][3];
+        r.rev = shl[1][0] + shl[1][1] + shl[1][2] + shl[1][3];
+        part[blockIdx.x] = r;
+    }
+}
+
+// RENDER_FS main() field math (html:395-420): scalar t per owned site, written in HOST layout
+// out[j*W + x]; NaN on solids.  Neighbour columns beyond the slab come from the ghost columns
+// (kept fresh by the caller), beyond the tunnel from CLAMP_TO_EDGE.
+template <typename T>
+struct FieldParams { T U0, maxS, cpMin, cpMax, vortScale; int mode; };
+
+template <typename T>
+__device__ __forceinline__ T field_value(const T *__restrict__ macro, const Geom &g, int i, int j, const FieldParams<T> &fp)
+{
+    const long mp = (long)g.nxl * g.pitch;
+    const long c = (long)i * g.pitch + j;
+    if (fp.mode == 0) {
+        const T ux = macro[mp + c], uy = macro[2 * mp + c];
+        const T s = wt_sqrt<T>(ux * ux + uy * uy) / fp.U0;
+        const T den = fp.maxS * T(0.92);
+        return s / (den < T(1e-6) ? T(1e-6) : den);
+    } else if (fp.mode == 1) {
+        const T cp = (macro[c] - T(1.0)) / (T(1.5) * fp.U0 * fp.U0);
+        const T r = fp.cpMax - fp.cpMin;
+        return (cp - fp.cpMin) / (r < T(1e-6) ? T(1e-6) : r);
+    }
+    const int gi = i + g.gi0;
+    const long cR = (gi + 1 < g.nx_g) ? c + g.pitch : c;
+    const long cL = (gi - 1 >= 0) ? c - g.pitch : c;
+    const long cU = (j + 1 < g.ny) ? c + 1 : c;
+    const long cD = (j - 1 >= 0) ? c - 1 : c;
+    const T dvydx = (macro[2 * mp + cR] - macro[2 * mp + cL]) * T(0.5);
+    const T duxdy = (macro[mp + cU] - macro[mp + cD]) * T(0.5);
+    const T vort = dvydx - duxdy;
+    const T den = fp.U0 * fp.vortScale;
+    return vort / (den < T(1e-6) ? T(1e-6) : den);
+}
+
+template <typename T>
+__global__ void k_field(const T *__restrict__ macro, const uint8_t *__restrict__ mask, Geom g,
+                        int i_own0, int W, FieldParams<T> fp, T *__restrict__ out)
+{
+    // 32x32 tiles: read along j (coalesced in device layout), write along x (coalesced in host layout)
+    __shared__ T tile[32][33];
+    const uint8_t *m = mask + g.pitch;
+    const int bj = blockIdx.x * 32, bx = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int x = bx + r, j = bj + threadIdx.x;
+        if (x < W && j < g.ny) {
+            const int i = i_own0 + x;
+            const long c = (long)i * g.pitch + j;
+            tile[r][threadIdx.x] = m[c] ? T(__builtin_nanf("")) : field_value<T>(macro, g, i, j, fp);
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int j = bj + r, x = bx + threadIdx.x;
+        if (x < W && j < g.ny) out[(long)j * W + x] = tile[threadIdx.x][r];
+    }
+}
+
+}  // namespace wt

@@ -1,0 +1,752 @@
+// windtunnel.hip — C-ABI implementation of libwindtunnel.so (see include/windtunnel.h).
+//
+// Replaces the JS LBM runtime of the reference (pages/airfoil_flow_lbm_aerolab.html:424-700):
+// texture/FBO ping-pong -> two SoA lattices in HBM; simStep -> step kernels on a HIP stream;
+// readMacro/updateFieldsFromMacro/computeForces/renderField -> on-demand kernels.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <vector>
+
+#include "../../include/windtunnel.h"
+#include "kernels.hpp"
+#include "step_fast.hpp"
+
+using namespace wt;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? WT_ERR_OOM : WT_ERR_HIP, "%s failed: %s (%s:%d)",   \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                              \
+    } while (0)
+
+#define NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess)                                                                          \
+            return fail(WT_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__,  \
+                        __LINE__);                                                                      \
+    } while (0)
+
+#define WT_TRY(expr)                \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != WT_OK) return rc_; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------
+enum Transport { TR_NONE = 0, TR_LOCAL = 1, TR_RCCL = 2 };
+
+struct wt_handle {
+    int nx_g = 0, ny = 0, dtype = WT_F32, device = 0;
+    int rank = 0, nranks = 1, halo = 0;
+    int x0 = 0, width = 0;       // owned global columns [x0, x0+width)
+    int gl = 0, gr = 0;          // ghost columns on the left / right
+    Geom g{};                    // local geometry
+    size_t esz = 4;              // element size
+    void *f[2] = {nullptr, nullptr};
+    int cur = 0;
+    void *macro = nullptr;       // 3 * nxl * pitch
+    uint8_t *mask = nullptr;     // (nxl+2) * pitch
+    uint8_t *tiles = nullptr;    // nxl * tiles_per_col
+    int tiles_per_col = 0;
+    void *stage = nullptr;       // device staging for layout conversion
+    size_t stage_bytes = 0;
+    void *partials = nullptr;    // reduction partials (device)
+    void *partials_host = nullptr;
+    hipStream_t s_compute = nullptr, s_comm = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_state = nullptr, ev_halo = nullptr;
+    bool mask_set = false, inited = false;
+    int ghost_valid = 0;         // ghost columns still exact (both sides)
+    long long steps_done = 0;
+    long long device_bytes = 0;
+    int transport = TR_NONE;
+    ncclComm_t comm = nullptr;
+    wt_handle *peer_l = nullptr, *peer_r = nullptr;   // TR_LOCAL
+};
+
+static const int kReduceBlocks = 1024;
+
+template <typename T> static T *fptr(wt_handle *h, int which) { return reinterpret_cast<T *>(h->f[which]); }
+
+static int ensure_stage(wt_handle *h, size_t bytes)
+{
+    if (h->stage_bytes >= bytes) return WT_OK;
+    if (h->stage) { HIP_TRY(hipFree(h->stage)); h->device_bytes -= (long long)h->stage_bytes; h->stage = nullptr; h->stage_bytes = 0; }
+    HIP_TRY(hipMalloc(&h->stage, bytes));
+    h->stage_bytes = bytes;
+    h->device_bytes += (long long)bytes;
+    return WT_OK;
+}
+
+static int check_handle(const wt_handle *h)
+{
+    if (!h) return fail(WT_ERR_ARG, "null handle");
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// life cycle
+// ------------------------------------------------------------------------------------------
+static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nranks, int halo, wt_handle **out)
+{
+    if (!out) return fail(WT_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (nx_g < 3 || ny < 3) return fail(WT_ERR_ARG, "lattice must be at least 3x3 (got %dx%d)", nx_g, ny);
+    if ((long long)nx_g * ny > (1LL << 33)) return fail(WT_ERR_ARG, "lattice too large");
+    if (dtype != WT_F32 && dtype != WT_F64) return fail(WT_ERR_ARG, "dtype must be WT_F32 or WT_F64");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(WT_ERR_ARG, "bad rank %d of %d", rank, nranks);
+    if (nranks > 1 && halo < 1) return fail(WT_ERR_ARG, "slab handles need halo >= 1");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(WT_ERR_HIP, "no HIP device available (%s); libwindtunnel has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(WT_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    HIP_TRY(hipSetDevice(device));
+
+    wt_handle *h = new (std::nothrow) wt_handle();
+    if (!h) return fail(WT_ERR_OOM, "host allocation failed");
+    h->nx_g = nx_g; h->ny = ny; h->dtype = dtype; h->device = device;
+    h->rank = rank; h->nranks = nranks;
+    h->x0 = (int)((long long)rank * nx_g / nranks);
+    const int x1 = (int)((long long)(rank + 1) * nx_g / nranks);
+    h->width = x1 - h->x0;
+    if (nranks > 1 && h->width < 2) { delete h; return fail(WT_ERR_ARG, "slab narrower than 2 columns"); }
+    if (nranks > 1 && halo > h->width) { delete h; return fail(WT_ERR_ARG, "halo %d wider than the slab (%d columns)", halo, h->width); }
+    h->halo = nranks > 1 ? halo : 0;
+    h->gl = (rank > 0) ? h->halo : 0;
+    h->gr = (rank < nranks - 1) ? h->halo : 0;
+    h->esz = dtype == WT_F32 ? 4 : 8;
+    Geom &g = h->g;
+    g.nxl = h->gl + h->width + h->gr;
+    g.ny = ny;
+    g.gi0 = h->x0 - h->gl;
+    g.nx_g = nx_g;
+    g.pitch = ((long)ny + 255) / 256 * 256;
+    g.plane = (long)(g.nxl + 2) * g.pitch;
+    h->tiles_per_col = (int)(g.pitch / tile_j_of(h->esz));
+
+    auto cleanup = [&](int rc) { wt_destroy(h); return rc; };
+    const size_t lat_bytes = (size_t)9 * g.plane * h->esz;
+    const size_t macro_bytes = (size_t)3 * g.nxl * g.pitch * h->esz;
+    const size_t mask_bytes = (size_t)(g.nxl + 2) * g.pitch;
+    const size_t tile_bytes = (size_t)g.nxl * h->tiles_per_col;
+#define CREATE_TRY(expr)                                                                               \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return cleanup(fail(e_ == hipErrorOutOfMemory ? WT_ERR_OOM : WT_ERR_HIP, "%s failed: %s",  \
+                                #expr, hipGetErrorString(e_)));                                        \
+    } while (0)
+    CREATE_TRY(hipMalloc(&h->f[0], lat_bytes));
+    CREATE_TRY(hipMalloc(&h->f[1], lat_bytes));
+    CREATE_TRY(hipMalloc(&h->macro, macro_bytes));
+    CREATE_TRY(hipMalloc((void **)&h->mask, mask_bytes));
+    CREATE_TRY(hipMalloc((void **)&h->tiles, tile_bytes));
+    CREATE_TRY(hipMalloc(&h->partials, kReduceBlocks * sizeof(ForcePartial)));
+    CREATE_TRY(hipHostMalloc(&h->partials_host, kReduceBlocks * sizeof(ForcePartial)));
+    h->device_bytes = (long long)(2 * lat_bytes + macro_bytes + mask_bytes + tile_bytes + kReduceBlocks * sizeof(ForcePartial));
+    int lo = 0, hi = 0;
+    CREATE_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CREATE_TRY(hipStreamCreateWithPriority(&h->s_compute, hipStreamNonBlocking, lo));
+    CREATE_TRY(hipStreamCreateWithPriority(&h->s_comm, hipStreamNonBlocking, hi));
+    CREATE_TRY(hipEventCreate(&h->ev_a));
+    CREATE_TRY(hipEventCreate(&h->ev_b));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
+    CREATE_TRY(hipMemsetAsync(h->f[0], 0, lat_bytes, h->s_compute));
+    CREATE_TRY(hipMemsetAsync(h->f[1], 0, lat_bytes, h->s_compute));
+    CREATE_TRY(hipMemsetAsync(h->macro, 0, macro_bytes, h->s_compute));
+    CREATE_TRY(hipMemsetAsync(h->mask, 0, mask_bytes, h->s_compute));
+    CREATE_TRY(hipMemsetAsync(h->tiles, 0, tile_bytes, h->s_compute));
+    CREATE_TRY(hipStreamSynchronize(h->s_compute));
+#undef CREATE_TRY
+    *out = h;
+    return WT_OK;
+}
+
+extern "C" int wt_create(int nx, int ny, int dtype, int device, wt_handle **out)
+{
+    return create_impl(nx, ny, dtype, device, 0, 1, 0, out);
+}
+
+extern "C" int wt_create_slab(int nx_global, int ny, int dtype, int device, int rank, int nranks, int halo,
+                              wt_handle **out)
+{
+    return create_impl(nx_global, ny, dtype, device, rank, nranks, halo, out);
+}
+
+extern "C" int wt_destroy(wt_handle *h)
+{
+    if (!h) return WT_OK;
+    (void)hipSetDevice(h->device);
+    if (h->s_compute) (void)hipStreamSynchronize(h->s_compute);
+    if (h->s_comm) (void)hipStreamSynchronize(h->s_comm);
+    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+    if (h->peer_l) h->peer_l->peer_r = nullptr;
+    if (h->peer_r) h->peer_r->peer_l = nullptr;
+    for (int i = 0; i < 2; i++) if (h->f[i]) (void)hipFree(h->f[i]);
+    if (h->macro) (void)hipFree(h->macro);
+    if (h->mask) (void)hipFree(h->mask);
+    if (h->tiles) (void)hipFree(h->tiles);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->partials) (void)hipFree(h->partials);
+    if (h->partials_host) (void)hipHostFree(h->partials_host);
+    if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+    if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->ev_state) (void)hipEventDestroy(h->ev_state);
+    if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
+    if (h->s_compute) (void)hipStreamDestroy(h->s_compute);
+    if (h->s_comm) (void)hipStreamDestroy(h->s_comm);
+    delete h;
+    return WT_OK;
+}
+
+extern "C" int wt_get_info(const wt_handle *h, wt_info *info)
+{
+    WT_TRY(check_handle(h));
+    if (!info) return fail(WT_ERR_ARG, "info is null");
+    info->nx_global = h->nx_g; info->ny = h->ny; info->dtype = h->dtype; info->device = h->device;
+    info->rank = h->rank; info->nranks = h->nranks; info->x0 = h->x0; info->width = h->width;
+    info->halo = h->halo; info->reserved = 0; info->steps_done = h->steps_done; info->device_bytes = h->device_bytes;
+    return WT_OK;
+}
+
+extern "C" const char *wt_last_error(void) { return g_err; }
+extern "C" const char *wt_version(void) { return "libwindtunnel 0.1 (gfx950, D2Q9 pull, column-major SoA)"; }
+
+extern "C" int wt_sync(wt_handle *h)
+{
+    WT_TRY(check_handle(h));
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_comm));
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// mask
+// ------------------------------------------------------------------------------------------
+__global__ void k_mask_rows_to_cols(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int ncols, int ny,
+                                    long pitch, long ld)
+{
+    // src[j*ld + x], x in [0,ncols) -> dst[x*pitch + j] as 0/1
+    __shared__ uint8_t tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int j = by + r, x = bx + threadIdx.x;
+        if (x < ncols && j < ny) tile[r][threadIdx.x] = src[(long)j * ld + x] ? 1 : 0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int x = bx + r, j = by + threadIdx.x;
+        if (x < ncols && j < ny) dst[(long)x * pitch + j] = tile[threadIdx.x][r];
+    }
+}
+
+extern "C" int wt_set_mask(wt_handle *h, const uint8_t *mask)
+{
+    WT_TRY(check_handle(h));
+    if (!mask) return fail(WT_ERR_ARG, "mask is null");
+    HIP_TRY(hipSetDevice(h->device));
+    const Geom &g = h->g;
+    // local columns -1 .. nxl  <->  global columns gi0-1 .. gi0+nxl, clipped to the tunnel
+    const int glo = g.gi0 - 1, ghi = g.gi0 + g.nxl;                  // inclusive
+    const int clo = glo < 0 ? 0 : glo, chi = ghi > g.nx_g - 1 ? g.nx_g - 1 : ghi;
+    const int ncols = chi - clo + 1;
+    WT_TRY(ensure_stage(h, (size_t)ncols * g.ny));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    HIP_TRY(hipMemcpy2D(h->stage, (size_t)ncols, mask + clo, (size_t)g.nx_g, (size_t)ncols, (size_t)g.ny,
+                        hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(h->mask, 0, (size_t)(g.nxl + 2) * g.pitch, h->s_compute));
+    dim3 blk(32, 8), grd((ncols + 31) / 32, (g.ny + 31) / 32);
+    // destination: local column (clo - g.gi0) lives at row (clo - g.gi0 + 1) of the padded mask
+    uint8_t *dst = h->mask + (long)(clo - g.gi0 + 1) * g.pitch;
+    hipLaunchKernelGGL(k_mask_rows_to_cols, grd, blk, 0, h->s_compute, (const uint8_t *)h->stage, dst, ncols, g.ny,
+                       g.pitch, (long)ncols);
+    HIP_TRY(hipGetLastError());
+    WT_TRY(classify_tiles(h->mask, h->tiles, g, h->tiles_per_col, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    h->mask_set = true;
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// init
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int init_impl(wt_handle *h, double u0)
+{
+    // html:474-490: JS doubles, rounded to the storage type
+    const double w0 = 4.0 / 9.0, ws = 1.0 / 9.0, wd = 1.0 / 36.0;
+    Init9<T> iv;
+    for (int k = 0; k < 9; k++) {
+        const double w = (k == 0) ? w0 : (k <= 4 ? ws : wd);
+        const double eu = ex_of(k) * u0, uu = u0 * u0;
+        iv.v[k] = (T)(w * (1 + 3 * eu + 4.5 * eu * eu - 1.5 * uu));
+    }
+    iv.u0 = (T)u0;
+    hipLaunchKernelGGL(k_fill_equilibrium<T>, dim3(2048), dim3(256), 0, h->s_compute, fptr<T>(h, 0), fptr<T>(h, 1),
+                       reinterpret_cast<T *>(h->macro), h->g, iv);
+    HIP_TRY(hipGetLastError());
+    return WT_OK;
+}
+
+extern "C" int wt_init_equilibrium(wt_handle *h, double u0)
+{
+    WT_TRY(check_handle(h));
+    HIP_TRY(hipSetDevice(h->device));
+    WT_TRY(h->dtype == WT_F32 ? init_impl<float>(h, u0) : init_impl<double>(h, u0));
+    h->cur = 0;
+    h->inited = true;
+    h->steps_done = 0;
+    h->ghost_valid = h->halo;     // a uniform state is exact everywhere, ghosts included
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stepping
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_step(wt_handle *h, int i_begin, int i_end, double tau, double u0, bool emit, hipStream_t st)
+{
+    if (i_end <= i_begin) return WT_OK;
+    return step_columns<T>(fptr<T>(h, h->cur), fptr<T>(h, 1 - h->cur), reinterpret_cast<T *>(h->macro), h->mask,
+                           h->tiles, h->tiles_per_col, h->g, i_begin, i_end, (T)tau, (T)u0, emit, st);
+}
+
+static int launch_step_any(wt_handle *h, int i_begin, int i_end, double tau, double u0, bool emit, hipStream_t st)
+{
+    int rc = h->dtype == WT_F32 ? launch_step<float>(h, i_begin, i_end, tau, u0, emit, st)
+                                : launch_step<double>(h, i_begin, i_end, tau, u0, emit, st);
+    if (rc != WT_OK) return fail(rc, "step kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return WT_OK;
+}
+
+// byte ranges of `ncol` whole columns starting at local column `i` in population k of lattice `which`
+static inline char *col_ptr(wt_handle *h, int which, int k, int i)
+{
+    return reinterpret_cast<char *>(h->f[which]) + ((size_t)k * h->g.plane + (size_t)(i + 1) * h->g.pitch) * h->esz;
+}
+
+// Refresh this slab's ghost columns from its neighbours' owned edge columns (lattice `cur`).
+// TR_RCCL: grouped send/recv on the comm stream.  Ghost columns are contiguous per population
+// (column-major layout), so the lattice itself is the send and the receive buffer.
+static int exchange_rccl(wt_handle *h)
+{
+    const size_t count = (size_t)h->halo * h->g.pitch;   // elements per population per side
+    const ncclDataType_t dt = h->dtype == WT_F32 ? ncclFloat32 : ncclFloat64;
+    NCCL_TRY(ncclGroupStart());
+    for (int k = 0; k < 9; k++) {
+        if (h->gl) {   // left neighbour: send my first `halo` owned columns, receive my left ghosts
+            NCCL_TRY(ncclSend(col_ptr(h, h->cur, k, h->gl), count, dt, h->rank - 1, h->comm, h->s_comm));
+            NCCL_TRY(ncclRecv(col_ptr(h, h->cur, k, 0), count, dt, h->rank - 1, h->comm, h->s_comm));
+        }
+        if (h->gr) {   // right neighbour: send my last `halo` owned columns, receive my right ghosts
+            NCCL_TRY(ncclSend(col_ptr(h, h->cur, k, h->gl + h->width - h->halo), count, dt, h->rank + 1, h->comm, h->s_comm));
+            NCCL_TRY(ncclRecv(col_ptr(h, h->cur, k, h->gl + h->width), count, dt, h->rank + 1, h->comm, h->s_comm));
+        }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return WT_OK;
+}
+
+// TR_LOCAL: pull the ghost columns from the peers' lattices with peer copies on MY comm stream.
+// The caller guarantees the peers' `cur` lattices are final (wt_step_group event-joins them).
+static int exchange_local(wt_handle *h)
+{
+    const size_t bytes = (size_t)h->halo * h->g.pitch * h->esz;
+    for (int k = 0; k < 9; k++) {
+        if (h->gl) {
+            wt_handle *p = h->peer_l;
+            HIP_TRY(hipMemcpyPeerAsync(col_ptr(h, h->cur, k, 0), h->device,
+                                       col_ptr(p, p->cur, k, p->gl + p->width - p->halo), p->device, bytes, h->s_comm));
+        }
+        if (h->gr) {
+            wt_handle *p = h->peer_r;
+            HIP_TRY(hipMemcpyPeerAsync(col_ptr(h, h->cur, k, h->gl + h->width), h->device,
+                                       col_ptr(p, p->cur, k, p->gl), p->device, bytes, h->s_comm));
+        }
+    }
+    return WT_OK;
+}
+
+static int check_steppable(wt_handle *h, int nsteps, double tau, double u0)
+{
+    WT_TRY(check_handle(h));
+    if (nsteps < 0) return fail(WT_ERR_ARG, "nsteps < 0");
+    if (!(tau > 0.0) || !std::isfinite(tau)) return fail(WT_ERR_ARG, "tau must be positive and finite");
+    if (!std::isfinite(u0)) return fail(WT_ERR_ARG, "u0 must be finite");
+    if (!h->inited) return fail(WT_ERR_STATE, "wt_init_equilibrium (or wt_write_f) has not been called");
+    if (!h->mask_set) return fail(WT_ERR_STATE, "wt_set_mask has not been called");
+    return WT_OK;
+}
+
+// One step of one handle.  If the ghosts are exhausted the halo exchange is overlapped with the
+// interior columns: [exchange on s_comm]  ||  [interior on s_compute]  ->  edge strips.
+static int step_once(wt_handle *h, double tau, double u0, bool emit)
+{
+    const Geom &g = h->g;
+    if (h->nranks == 1 || h->transport == TR_NONE) {
+        if (h->nranks > 1) return fail(WT_ERR_STATE, "slab handle has no transport (wt_comm_init_rank / wt_link_local)");
+        WT_TRY(launch_step_any(h, 0, g.nxl, tau, u0, emit, h->s_compute));
+    } else if (h->ghost_valid > 0) {
+        WT_TRY(launch_step_any(h, 0, g.nxl, tau, u0, emit, h->s_compute));
+        h->ghost_valid -= 1;
+    } else {
+        // ghosts stale: refresh them while the columns that do not read them are updated
+        HIP_TRY(hipEventRecord(h->ev_state, h->s_compute));
+        HIP_TRY(hipStreamWaitEvent(h->s_comm, h->ev_state, 0));
+        if (h->transport == TR_RCCL) WT_TRY(exchange_rccl(h)); else WT_TRY(exchange_local(h));
+        HIP_TRY(hipEventRecord(h->ev_halo, h->s_comm));
+        const int ib = h->gl ? h->gl + 1 : 0;                     // first column whose stencil avoids the left ghosts
+        const int ie = h->gr ? h->gl + h->width - 1 : g.nxl;      // one past the last such column
+        WT_TRY(launch_step_any(h, ib, ie, tau, u0, emit, h->s_compute));
+        HIP_TRY(hipStreamWaitEvent(h->s_compute, h->ev_halo, 0));
+        if (h->gl) WT_TRY(launch_step_any(h, 0, ib, tau, u0, emit, h->s_compute));
+        if (h->gr) WT_TRY(launch_step_any(h, ie, g.nxl, tau, u0, emit, h->s_compute));
+        h->ghost_valid = h->halo - 1;
+    }
+    h->cur = 1 - h->cur;
+    h->steps_done += 1;
+    return WT_OK;
+}
+
+extern "C" int wt_step(wt_handle *h, int nsteps, double tau, double u0)
+{
+    WT_TRY(check_steppable(h, nsteps, tau, u0));
+    if (h->transport == TR_LOCAL) return fail(WT_ERR_STATE, "locally linked slabs are stepped with wt_step_group");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int s = 0; s < nsteps; s++) WT_TRY(step_once(h, tau, u0, s == nsteps - 1));
+    return WT_OK;
+}
+
+extern "C" int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, float *elapsed_ms)
+{
+    WT_TRY(check_steppable(h, nsteps, tau, u0));
+    if (!elapsed_ms) return fail(WT_ERR_ARG, "elapsed_ms is null");
+    if (h->transport == TR_LOCAL) return fail(WT_ERR_STATE, "locally linked slabs are stepped with wt_step_group");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipEventRecord(h->ev_a, h->s_compute));
+    for (int s = 0; s < nsteps; s++) WT_TRY(step_once(h, tau, u0, s == nsteps - 1));
+    HIP_TRY(hipEventRecord(h->ev_b, h->s_compute));
+    HIP_TRY(hipEventSynchronize(h->ev_b));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev_a, h->ev_b));
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// transports
+// ------------------------------------------------------------------------------------------
+extern "C" int wt_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(WT_ERR_ARG, "id_out is null");
+    static_assert(sizeof(ncclUniqueId) <= WT_COMM_ID_BYTES, "ncclUniqueId larger than WT_COMM_ID_BYTES");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memset(id_out, 0, WT_COMM_ID_BYTES);
+    memcpy(id_out, &id, sizeof(id));
+    return WT_OK;
+}
+
+extern "C" int wt_comm_init_rank(wt_handle *h, const void *id_in)
+{
+    WT_TRY(check_handle(h));
+    if (!id_in) return fail(WT_ERR_ARG, "id is null");
+    if (h->nranks < 2) return fail(WT_ERR_STATE, "not a slab handle");
+    if (h->transport != TR_NONE) return fail(WT_ERR_STATE, "handle already has a transport");
+    HIP_TRY(hipSetDevice(h->device));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof(id));
+    NCCL_TRY(ncclCommInitRank(&h->comm, h->nranks, id, h->rank));
+    h->transport = TR_RCCL;
+    return WT_OK;
+}
+
+extern "C" int wt_link_local(wt_handle **hs, int n)
+{
+    if (!hs || n < 2) return fail(WT_ERR_ARG, "need at least two slab handles");
+    for (int r = 0; r < n; r++) {
+        wt_handle *h = hs[r];
+        WT_TRY(check_handle(h));
+        if (h->nranks != n || h->rank != r) return fail(WT_ERR_ARG, "handle %d is rank %d of %d", r, h->rank, h->nranks);
+        if (h->transport != TR_NONE) return fail(WT_ERR_STATE, "handle %d already has a transport", r);
+        if (h->nx_g != hs[0]->nx_g || h->ny != hs[0]->ny || h->dtype != hs[0]->dtype || h->halo != hs[0]->halo)
+            return fail(WT_ERR_ARG, "slab %d does not match slab 0", r);
+    }
+    for (int r = 0; r < n; r++) {
+        wt_handle *h = hs[r];
+        h->peer_l = r > 0 ? hs[r - 1] : nullptr;
+        h->peer_r = r < n - 1 ? hs[r + 1] : nullptr;
+        h->transport = TR_LOCAL;
+        for (wt_handle *p : {h->peer_l, h->peer_r}) {
+            if (p && p->device != h->device) {
+                int can = 0;
+                HIP_TRY(hipDeviceCanAccessPeer(&can, h->device, p->device));
+                if (can) {
+                    HIP_TRY(hipSetDevice(h->device));
+                    hipError_t e = hipDeviceEnablePeerAccess(p->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                        return fail(WT_ERR_HIP, "hipDeviceEnablePeerAccess failed: %s", hipGetErrorString(e));
+                    (void)hipGetLastError();
+                }
+            }
+        }
+    }
+    return WT_OK;
+}
+
+extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, double u0)
+{
+    if (!hs || n < 1) return fail(WT_ERR_ARG, "no handles");
+    for (int r = 0; r < n; r++) {
+        WT_TRY(check_steppable(hs[r], nsteps, tau, u0));
+        if (n > 1 && hs[r]->transport != TR_LOCAL) return fail(WT_ERR_STATE, "handle %d is not locally linked", r);
+        if (hs[r]->ghost_valid != hs[0]->ghost_valid || hs[r]->steps_done != hs[0]->steps_done)
+            return fail(WT_ERR_STATE, "slabs are not at the same step");
+    }
+    for (int s = 0; s < nsteps; s++) {
+        const bool emit = (s == nsteps - 1);
+        if (n > 1 && hs[0]->ghost_valid == 0) {
+            // every slab's comm stream must see its neighbours' finished lattices
+            for (int r = 0; r < n; r++) {
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                HIP_TRY(hipEventRecord(hs[r]->ev_state, hs[r]->s_compute));
+            }
+            for (int r = 0; r < n; r++) {
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_comm, hs[r]->peer_l->ev_state, 0));
+                if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_comm, hs[r]->peer_r->ev_state, 0));
+            }
+        }
+        for (int r = 0; r < n; r++) {
+            HIP_TRY(hipSetDevice(hs[r]->device));
+            WT_TRY(step_once(hs[r], tau, u0, emit));
+        }
+        if (n > 1 && hs[0]->ghost_valid == hs[0]->halo - 1) {
+            // the peers' NEXT step overwrites the lattice my copies just read: make their compute
+            // streams wait for my halo copies (ev_halo was recorded by step_once)
+            for (int r = 0; r < n; r++) {
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_l->ev_halo, 0));
+                if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_r->ev_halo, 0));
+            }
+        }
+    }
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// populations in / out
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int read_plane(wt_handle *h, const T *src_cols, T *host_dst)
+{
+    const Geom &g = h->g;
+    const size_t bytes = (size_t)h->width * g.ny * sizeof(T);
+    WT_TRY(ensure_stage(h, bytes));
+    dim3 blk(32, 8), grd((g.ny + 31) / 32, (h->width + 31) / 32);
+    hipLaunchKernelGGL(k_cols_to_rows<T>, grd, blk, 0, h->s_compute, src_cols, reinterpret_cast<T *>(h->stage), h->gl,
+                       h->width, g.ny, g.pitch);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_dst, h->stage, bytes, hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    return WT_OK;
+}
+
+template <typename T>
+static int read_f_impl(wt_handle *h, void *out)
+{
+    const size_t n = (size_t)h->width * h->g.ny;
+    for (int k = 0; k < 9; k++)
+        WT_TRY(read_plane<T>(h, fptr<T>(h, h->cur) + k * h->g.plane + h->g.pitch, reinterpret_cast<T *>(out) + k * n));
+    return WT_OK;
+}
+
+extern "C" int wt_read_f(wt_handle *h, void *f_out)
+{
+    WT_TRY(check_handle(h));
+    if (!f_out) return fail(WT_ERR_ARG, "f_out is null");
+    if (!h->inited) return fail(WT_ERR_STATE, "no state to read");
+    HIP_TRY(hipSetDevice(h->device));
+    return h->dtype == WT_F32 ? read_f_impl<float>(h, f_out) : read_f_impl<double>(h, f_out);
+}
+
+template <typename T>
+static int write_f_impl(wt_handle *h, const void *in)
+{
+    const Geom &g = h->g;
+    const size_t n = (size_t)h->width * g.ny;
+    WT_TRY(ensure_stage(h, n * sizeof(T)));
+    dim3 blk(32, 8), grd((h->width + 31) / 32, (g.ny + 31) / 32);
+    for (int k = 0; k < 9; k++) {
+        HIP_TRY(hipMemcpyAsync(h->stage, reinterpret_cast<const T *>(in) + k * n, n * sizeof(T), hipMemcpyHostToDevice,
+                               h->s_compute));
+        hipLaunchKernelGGL(k_rows_to_cols<T>, grd, blk, 0, h->s_compute, reinterpret_cast<const T *>(h->stage),
+                           fptr<T>(h, h->cur) + k * g.plane + g.pitch, h->gl, h->width, g.ny, g.pitch, (long)h->width);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->s_compute));
+    }
+    return WT_OK;
+}
+
+extern "C" int wt_write_f(wt_handle *h, const void *f_in)
+{
+    WT_TRY(check_handle(h));
+    if (!f_in) return fail(WT_ERR_ARG, "f_in is null");
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->inited) {   // make pads / ghosts finite
+        WT_TRY(h->dtype == WT_F32 ? init_impl<float>(h, 0.0) : init_impl<double>(h, 0.0));
+        h->cur = 0;
+    }
+    WT_TRY(h->dtype == WT_F32 ? write_f_impl<float>(h, f_in) : write_f_impl<double>(h, f_in));
+    h->inited = true;
+    h->ghost_valid = 0;      // ghosts must be refreshed from the neighbours before the next step
+    h->steps_done = 0;
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// macro read-back, reductions, field
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int read_macro_impl(wt_handle *h, void *rho, void *ux, void *uy)
+{
+    const long mp = (long)h->g.nxl * h->g.pitch;
+    const T *m = reinterpret_cast<const T *>(h->macro);
+    void *dst[3] = {rho, ux, uy};
+    for (int a = 0; a < 3; a++)
+        if (dst[a]) WT_TRY(read_plane<T>(h, m + a * mp, reinterpret_cast<T *>(dst[a])));
+    return WT_OK;
+}
+
+extern "C" int wt_read_macro(wt_handle *h, void *rho, void *ux, void *uy)
+{
+    WT_TRY(check_handle(h));
+    if (!h->inited) return fail(WT_ERR_STATE, "no state to read");
+    HIP_TRY(hipSetDevice(h->device));
+    return h->dtype == WT_F32 ? read_macro_impl<float>(h, rho, ux, uy) : read_macro_impl<double>(h, rho, ux, uy);
+}
+
+extern "C" int wt_reduce_ranges(wt_handle *h, double u0, double *max_s, double *cp_min, double *cp_max)
+{
+    WT_TRY(check_handle(h));
+    if (!max_s || !cp_min || !cp_max) return fail(WT_ERR_ARG, "null output");
+    if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (!(u0 != 0.0)) return fail(WT_ERR_ARG, "u0 must be non-zero");
+    HIP_TRY(hipSetDevice(h->device));
+    const long total = (long)h->width * h->g.ny;
+    int nb = (int)((total + 255) / 256);
+    if (nb > kReduceBlocks) nb = kReduceBlocks;
+    RangePartial *dp = reinterpret_cast<RangePartial *>(h->partials);
+    if (h->dtype == WT_F32)
+        hipLaunchKernelGGL(k_ranges<float>, dim3(nb), dim3(256), 0, h->s_compute, (const float *)h->macro, h->mask, h->g,
+                           h->gl, h->width, u0, dp);
+    else
+        hipLaunchKernelGGL(k_ranges<double>, dim3(nb), dim3(256), 0, h->s_compute, (const double *)h->macro, h->mask,
+                           h->g, h->gl, h->width, u0, dp);
+    HIP_TRY(hipGetLastError());
+    RangePartial *hp = reinterpret_cast<RangePartial *>(h->partials_host);
+    HIP_TRY(hipMemcpyAsync(hp, dp, nb * sizeof(RangePartial), hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    double mx = 0.0, cmin = std::numeric_limits<double>::infinity(), cmax = -cmin;
+    for (int b = 0; b < nb; b++) {
+        if (hp[b].max_s > mx) mx = hp[b].max_s;
+        if (hp[b].cp_min < cmin) cmin = hp[b].cp_min;
+        if (hp[b].cp_max > cmax) cmax = hp[b].cp_max;
+    }
+    *max_s = mx; *cp_min = cmin; *cp_max = cmax;
+    return WT_OK;
+}
+
+extern "C" int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, int64_t *rev)
+{
+    WT_TRY(check_handle(h));
+    if (!fx || !fy || !surf || !rev) return fail(WT_ERR_ARG, "null output");
+    if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    HIP_TRY(hipSetDevice(h->device));
+    const long total = (long)h->width * h->g.ny;
+    int nb = (int)((total + 255) / 256);
+    if (nb > kReduceBlocks) nb = kReduceBlocks;
+    ForcePartial *dp = reinterpret_cast<ForcePartial *>(h->partials);
+    if (h->dtype == WT_F32)
+        hipLaunchKernelGGL(k_forces<float>, dim3(nb), dim3(256), 0, h->s_compute, (const float *)h->macro, h->mask, h->g,
+                           h->gl, h->width, dp);
+    else
+        hipLaunchKernelGGL(k_forces<double>, dim3(nb), dim3(256), 0, h->s_compute, (const double *)h->macro, h->mask,
+                           h->g, h->gl, h->width, dp);
+    HIP_TRY(hipGetLastError());
+    ForcePartial *hp = reinterpret_cast<ForcePartial *>(h->partials_host);
+    HIP_TRY(hipMemcpyAsync(hp, dp, nb * sizeof(ForcePartial), hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    double sx = 0.0, sy = 0.0;
+    long long ns = 0, nr = 0;
+    for (int b = 0; b < nb; b++) { sx += hp[b].fx; sy += hp[b].fy; ns += hp[b].surf; nr += hp[b].rev; }
+    *fx = sx; *fy = sy; *surf = ns; *rev = nr;
+    return WT_OK;
+}
+
+template <typename T>
+static int field_impl(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max, double vs, void *out)
+{
+    const Geom &g = h->g;
+    const size_t bytes = (size_t)h->width * g.ny * sizeof(T);
+    WT_TRY(ensure_stage(h, bytes));
+    FieldParams<T> fp;
+    fp.U0 = (T)u0; fp.maxS = (T)max_s; fp.cpMin = (T)cp_min; fp.cpMax = (T)cp_max; fp.vortScale = (T)vs; fp.mode = mode;
+    dim3 blk(32, 8), grd((g.ny + 31) / 32, (h->width + 31) / 32);
+    hipLaunchKernelGGL(k_field<T>, grd, blk, 0, h->s_compute, reinterpret_cast<const T *>(h->macro), h->mask, g, h->gl,
+                       h->width, fp, reinterpret_cast<T *>(h->stage));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    return WT_OK;
+}
+
+extern "C" int wt_field(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
+                        double vort_scale, void *t_out)
+{
+    WT_TRY(check_handle(h));
+    if (!t_out) return fail(WT_ERR_ARG, "t_out is null");
+    if (mode < 0 || mode > 2) return fail(WT_ERR_ARG, "mode must be 0 (speed), 1 (cp) or 2 (vort)");
+    if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (mode == WT_FIELD_VORT && h->nranks > 1)
+        return fail(WT_ERR_STATE, "vorticity on a slab handle needs macro ghost columns (not implemented yet)");
+    HIP_TRY(hipSetDevice(h->device));
+    return h->dtype == WT_F32 ? field_impl<float>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, t_out)
+                              : field_impl<double>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, t_out);
+}
+
+extern "C" int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
+                              double vort_scale, uint8_t *rgba_out)
+{
+    (void)mode; (void)u0; (void)max_s; (void)cp_min; (void)cp_max; (void)vort_scale; (void)rgba_out;
+    WT_TRY(check_handle(h));
+    return fail(WT_ERR_STATE, "wt_render_rgba: colour-map renderer not built yet (SURVEY §8 f2)");
+}

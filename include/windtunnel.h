@@ -1,0 +1,164 @@
+/*
+ * windtunnel.h — C-ABI of libwindtunnel.so: the MI355X-native D2Q9 lattice-
+ * Boltzmann wind tunnel that replaces the WebGL2 component of
+ * 583phoenix-hue/Airfoil-CFD-Tool, pages/airfoil_flow_lbm_aerolab.html (cited
+ * below as html:LINE).  The reference exports nothing (one IIFE, html:61); the
+ * entry points below are its de-facto internal interface, one export per
+ * reference function, so that a ctypes/cffi binding can stand where the page's
+ * JS runtime stood.
+ *
+ * Conventions
+ *   - every function returns 0 (WT_OK) or a negative wt_status; the message for
+ *     the calling thread's last failure is wt_last_error().  No exceptions and
+ *     no aborts cross this boundary.
+ *   - host arrays are C-contiguous, shape [NY][W] (row 0 = bottom of the tunnel,
+ *     x fastest), W = the handle's owned column count (W = NX for a whole-lattice
+ *     handle; see wt_get_info).  Population arrays are [9][NY][W] in the
+ *     reference's direction order (html:238-248).  Element type = the handle's
+ *     dtype (float for WT_F32, double for WT_F64).  The caller owns every host
+ *     buffer; the library owns all device memory, streams and communicators.
+ *   - a handle is driven by one host thread at a time.  wt_step only enqueues
+ *     work on the handle's HIP streams and returns; every read-back and wt_sync
+ *     block until the device has finished.
+ *   - there is NO CPU fallback: without a usable HIP device wt_create fails
+ *     with WT_ERR_HIP.
+ */
+#ifndef WINDTUNNEL_H
+#define WINDTUNNEL_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wt_handle wt_handle;
+
+typedef enum wt_status {
+    WT_OK = 0,
+    WT_ERR_ARG = -1,     /* bad argument / shape */
+    WT_ERR_HIP = -2,     /* HIP runtime failure (no device, launch error, ...) */
+    WT_ERR_RCCL = -3,    /* RCCL failure */
+    WT_ERR_OOM = -4,     /* device or host allocation failed */
+    WT_ERR_STATE = -5    /* call not valid in the handle's current state */
+} wt_status;
+
+typedef enum wt_dtype { WT_F32 = 0, WT_F64 = 1 } wt_dtype;
+
+/* html:32-36, 527, 953: the page's field selector */
+typedef enum wt_field_mode { WT_FIELD_SPEED = 0, WT_FIELD_CP = 1, WT_FIELD_VORT = 2 } wt_field_mode;
+
+typedef struct wt_info {
+    int32_t nx_global;   /* lattice columns of the whole tunnel                   */
+    int32_t ny;          /* lattice rows                                           */
+    int32_t dtype;       /* wt_dtype                                               */
+    int32_t device;      /* HIP device ordinal                                     */
+    int32_t rank;        /* slab index, 0 = inlet side                             */
+    int32_t nranks;      /* number of column slabs                                 */
+    int32_t x0;          /* first owned global column                              */
+    int32_t width;       /* owned columns W                                        */
+    int32_t halo;        /* ghost columns kept on each interior side               */
+    int32_t reserved;
+    int64_t steps_done;  /* simStep count since wt_init_equilibrium / wt_write_f   */
+    int64_t device_bytes;/* device memory held by the handle                       */
+} wt_info;
+
+/* ---- life cycle ------------------------------------------------------------ */
+
+/* Replaces the WebGL context + texture/FBO creation (html:87-95, 438-469, 492-500).
+ * One handle = the whole NX x NY lattice on one GPU. */
+int wt_create(int nx, int ny, int dtype, int device, wt_handle **out);
+
+/* One column slab of a lattice that is split over `nranks` handles (one GPU
+ * each): rank r owns global columns [r*NX/nranks, (r+1)*NX/nranks) plus `halo`
+ * ghost columns on each interior side, refreshed every `halo` steps.  New design
+ * (the reference is single-context); SURVEY.md §8e. */
+int wt_create_slab(int nx_global, int ny, int dtype, int device,
+                   int rank, int nranks, int halo, wt_handle **out);
+
+int wt_destroy(wt_handle *h);
+int wt_get_info(const wt_handle *h, wt_info *info);
+const char *wt_last_error(void);
+const char *wt_version(void);
+
+/* ---- ghost-column transport for slab handles -------------------------------- */
+
+/* RCCL over xGMI, one process per GPU: rank 0 calls wt_comm_unique_id, the host
+ * broadcasts the WT_COMM_ID_BYTES bytes (e.g. torch.distributed), then EVERY
+ * rank calls wt_comm_init_rank (collective). */
+#define WT_COMM_ID_BYTES 128
+int wt_comm_unique_id(void *id_out);
+int wt_comm_init_rank(wt_handle *h, const void *id);
+
+/* In-process transport: all slabs of one tunnel live in the calling process
+ * (any mix of devices); ghost columns move by peer copies.  `hs` are the
+ * nranks slab handles ordered by rank.  Stepping then goes through
+ * wt_step_group, which advances every slab in lock-step. */
+int wt_link_local(wt_handle **hs, int n);
+int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, double u0);
+
+/* ---- state ------------------------------------------------------------------ */
+
+/* Replaces makeMaskTex/applyGeometry's upload (html:448-458, 579-586).
+ * `mask` is the WHOLE tunnel's mask, [NY][NX_global] uint8, non-zero = solid;
+ * a slab handle takes the columns it needs (owned + ghost).  The flow state is
+ * NOT re-initialised (html:579-586). */
+int wt_set_mask(wt_handle *h, const uint8_t *mask);
+
+/* Replaces initSim/equilibriumInitData (html:474-500): every site, solids
+ * included, gets feq(rho=1,u=(u0,0)) evaluated in double and stored in the
+ * handle's dtype; macro = (1,u0,0). */
+int wt_init_equilibrium(wt_handle *h, double u0);
+
+/* Replaces `nsteps` x simStep (html:510-525) = STEP_FS main() (html:283-360) per
+ * site: pull-stream, half-way bounce-back, far-field/outlet BC, moments, clamp,
+ * BGK.  tau and u0 are the shader uniforms (html:521-522), converted to the
+ * handle's dtype.  The LAST step of the call also stores the macroscopic
+ * fields (rho,ux,uy) that the reference writes into texC (html:357-359). */
+int wt_step(wt_handle *h, int nsteps, double tau, double u0);
+
+/* As wt_step, bracketed by HIP events on the stream the step kernels run on;
+ * blocks, and returns the elapsed device time in milliseconds. */
+int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, float *elapsed_ms);
+
+/* Test / checkpoint access to the populations, [9][NY][W]. */
+int wt_read_f(wt_handle *h, void *f_out);
+int wt_write_f(wt_handle *h, const void *f_in);
+
+/* ---- read-backs and reductions ---------------------------------------------- */
+
+/* Replaces readMacro (html:547-552): rho, ux, uy of the last step, each [NY][W]. */
+int wt_read_macro(wt_handle *h, void *rho, void *ux, void *uy);
+
+/* Replaces the range scan of updateFieldsFromMacro (html:596-614), in doubles
+ * over fluid sites: max_s = max hypot(ux,uy)/u0 over values < 4 (0 if none);
+ * cp range over -4 < cp < 1.2 with cp=(rho-1)/(1.5 u0^2) (+inf/-inf if none).
+ * Partial result of the handle's owned columns; the "keep the previous value"
+ * rule (html:611-613) stays with the caller, as in the page. */
+int wt_reduce_ranges(wt_handle *h, double u0, double *max_s, double *cp_min, double *cp_max);
+
+/* Replaces computeForces' two scans (html:650-698), raw sums over the fluid/
+ * solid faces whose FLUID cell is owned: fx,fy = sum of (rho_fluid/3) * (unit
+ * vector from the fluid cell into the solid); surf = face count; rev = faces
+ * whose fluid cell has ux < 0.  Coefficients and smoothing stay with the caller
+ * (html:676-679, 699). */
+int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, int64_t *rev);
+
+/* Replaces RENDER_FS main()'s field math (html:395-420): the scalar t handed to
+ * the colour map, [NY][W], NaN on solid sites.  max_s/cp_min/cp_max are the
+ * uniforms of html:540-542, vort_scale html:528/543. */
+int wt_field(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
+             double vort_scale, void *t_out);
+
+/* Replaces RENDER_FS's colour maps (html:371-393, 397): RGBA8 image, [NY][W][4],
+ * row 0 = bottom. */
+int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
+                   double vort_scale, uint8_t *rgba_out);
+
+int wt_sync(wt_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WINDTUNNEL_H */
