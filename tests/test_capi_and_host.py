@@ -1,0 +1,77 @@
+"""C-ABI surface and host logic that need no GPU."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_exports():
+    with open(os.path.join(ROOT, "include", "windtunnel.h")) as fh:
+        txt = fh.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(wt_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    names = _declared_exports()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libwindtunnel.so lacks {n}"
+    from airfoil_cfd_tool_amd._capi import EXPORTS
+    assert sorted(EXPORTS) == names
+    assert b"libwindtunnel" in lib.wt_version()
+
+
+def test_argument_errors_without_a_gpu(pkg):
+    lib = pkg.load_library()
+    h = ctypes.c_void_p()
+    assert lib.wt_create(2, 2, 0, 0, ctypes.byref(h)) == -1          # WT_ERR_ARG before any device call
+    assert b"3x3" in lib.wt_last_error()
+    assert lib.wt_create(64, 64, 7, 0, ctypes.byref(h)) == -1
+    assert lib.wt_create_slab(64, 64, 0, 0, 3, 2, 1, ctypes.byref(h)) == -1
+    assert lib.wt_create_slab(64, 64, 0, 0, 0, 2, 0, ctypes.byref(h)) == -1
+    assert lib.wt_destroy(None) == 0
+    assert lib.wt_step(None, 1, 0.58, 0.06) == -1
+    assert lib.wt_sync(None) == -1
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a HIP device the product path must fail loudly (no oracle / CPU route)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    with pytest.raises(pkg.WTError) as ei:
+        pkg.Engine(64, 64)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+    import airfoil_cfd_tool_amd.windtunnel as wtmod
+    import airfoil_cfd_tool_amd._capi as capi
+    for mod in (wtmod, capi, pkg.geometry):
+        with open(mod.__file__) as fh:
+            src = fh.read()
+        assert not re.search(r"^\s*(import|from)\s+\S*(lbm_numpy|lbm_c\b|oracle)", src, flags=re.M)
+
+
+def test_stall_label_thresholds(pkg, oracle_np):
+    """html:869-884."""
+    for frac, want in ((0.0, "Attached"), (0.044, "Attached"), (0.045, "5% sep"), (0.2449, "24% sep"),
+                       (0.245, "STALL ≈ 25% sep"), (0.7, "STALL ≈ 70% sep")):
+        assert pkg.stall_label(frac) == want
+        assert oracle_np.stall_label(frac) == want
+
+
+def test_reynolds_and_tau(pkg):
+    assert round(pkg.reynolds(0.06, 320, 0.58)) == 391
+    tau = pkg.tau_from_reynolds(1e6, 0.06, 4096)
+    assert tau == pytest.approx(0.5004007, abs=1e-7)                   # SURVEY §8d cfg 5
+    assert pkg.reynolds(0.06, 4096, tau) == pytest.approx(1e6, rel=1e-9)
+    with pytest.raises(ValueError):
+        pkg.tau_from_reynolds(0.0, 0.06, 320)
