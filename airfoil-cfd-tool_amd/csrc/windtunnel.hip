@@ -408,23 +408,31 @@ static int check_steppable(wt_handle *h, int nsteps, double tau, double u0)
     return WT_OK;
 }
 
-// One step of one handle.  If the ghosts are exhausted the halo exchange is overlapped with the
-// interior columns: [exchange on s_comm]  ||  [interior on s_compute]  ->  edge strips.
-static int step_once(wt_handle *h, double tau, double u0, bool emit)
+// Enqueue the refresh of this slab's ghost columns (lattice `cur`) on its comm stream.
+static int halo_begin(wt_handle *h)
+{
+    HIP_TRY(hipEventRecord(h->ev_state, h->s_compute));
+    HIP_TRY(hipStreamWaitEvent(h->s_comm, h->ev_state, 0));
+    if (h->transport == TR_RCCL) WT_TRY(exchange_rccl(h)); else WT_TRY(exchange_local(h));
+    HIP_TRY(hipEventRecord(h->ev_halo, h->s_comm));
+    return WT_OK;
+}
+
+static inline bool needs_halo(const wt_handle *h) { return h->nranks > 1 && h->ghost_valid == 0; }
+
+// One step of one handle.  `refreshed`: halo_begin was enqueued for this step; the refresh is
+// overlapped with the interior columns:  [ghost refresh on s_comm] || [interior on s_compute]
+// -> edge strips once the ghosts have landed.
+static int step_compute(wt_handle *h, double tau, double u0, bool emit, bool refreshed)
 {
     const Geom &g = h->g;
-    if (h->nranks == 1 || h->transport == TR_NONE) {
-        if (h->nranks > 1) return fail(WT_ERR_STATE, "slab handle has no transport (wt_comm_init_rank / wt_link_local)");
+    if (h->nranks == 1) {
         WT_TRY(launch_step_any(h, 0, g.nxl, tau, u0, emit, h->s_compute));
-    } else if (h->ghost_valid > 0) {
+    } else if (!refreshed) {
+        if (h->ghost_valid <= 0) return fail(WT_ERR_STATE, "internal: stale ghost columns");
         WT_TRY(launch_step_any(h, 0, g.nxl, tau, u0, emit, h->s_compute));
         h->ghost_valid -= 1;
     } else {
-        // ghosts stale: refresh them while the columns that do not read them are updated
-        HIP_TRY(hipEventRecord(h->ev_state, h->s_compute));
-        HIP_TRY(hipStreamWaitEvent(h->s_comm, h->ev_state, 0));
-        if (h->transport == TR_RCCL) WT_TRY(exchange_rccl(h)); else WT_TRY(exchange_local(h));
-        HIP_TRY(hipEventRecord(h->ev_halo, h->s_comm));
         const int ib = h->gl ? h->gl + 1 : 0;                     // first column whose stencil avoids the left ghosts
         const int ie = h->gr ? h->gl + h->width - 1 : g.nxl;      // one past the last such column
         WT_TRY(launch_step_any(h, ib, ie, tau, u0, emit, h->s_compute));
@@ -436,6 +444,15 @@ static int step_once(wt_handle *h, double tau, double u0, bool emit)
     h->cur = 1 - h->cur;
     h->steps_done += 1;
     return WT_OK;
+}
+
+static int step_once(wt_handle *h, double tau, double u0, bool emit)
+{
+    if (h->nranks > 1 && h->transport == TR_NONE)
+        return fail(WT_ERR_STATE, "slab handle has no transport (wt_comm_init_rank / wt_link_local)");
+    const bool refresh = needs_halo(h);
+    if (refresh) WT_TRY(halo_begin(h));
+    return step_compute(h, tau, u0, emit, refresh);
 }
 
 extern "C" int wt_step(wt_handle *h, int nsteps, double tau, double u0)
@@ -533,8 +550,9 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
     }
     for (int s = 0; s < nsteps; s++) {
         const bool emit = (s == nsteps - 1);
-        if (n > 1 && hs[0]->ghost_valid == 0) {
-            // every slab's comm stream must see its neighbours' finished lattices
+        const bool refresh = n > 1 && hs[0]->ghost_valid == 0;
+        if (refresh) {
+            // every slab's comm stream must see its neighbours' finished lattices ...
             for (int r = 0; r < n; r++) {
                 HIP_TRY(hipSetDevice(hs[r]->device));
                 HIP_TRY(hipEventRecord(hs[r]->ev_state, hs[r]->s_compute));
@@ -544,14 +562,19 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
                 if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_comm, hs[r]->peer_l->ev_state, 0));
                 if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_comm, hs[r]->peer_r->ev_state, 0));
             }
+            // ... and ALL refreshes are enqueued before any slab flips its lattice index
+            for (int r = 0; r < n; r++) {
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                WT_TRY(halo_begin(hs[r]));
+            }
         }
         for (int r = 0; r < n; r++) {
             HIP_TRY(hipSetDevice(hs[r]->device));
-            WT_TRY(step_once(hs[r], tau, u0, emit));
+            WT_TRY(step_compute(hs[r], tau, u0, emit, refresh));
         }
-        if (n > 1 && hs[0]->ghost_valid == hs[0]->halo - 1) {
-            // the peers' NEXT step overwrites the lattice my copies just read: make their compute
-            // streams wait for my halo copies (ev_halo was recorded by step_once)
+        if (refresh) {
+            // the peers' NEXT step overwrites the lattice my copies just read: their compute
+            // streams wait for my halo copies
             for (int r = 0; r < n; r++) {
                 HIP_TRY(hipSetDevice(hs[r]->device));
                 if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_l->ev_halo, 0));

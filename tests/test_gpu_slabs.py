@@ -1,0 +1,97 @@
+"""GPU: column-slab decomposition inside libwindtunnel (ghost columns, deep halos, overlap of the
+halo refresh with the interior columns) against the single-lattice run.  All slabs live on the one
+GPU of the test box and move ghost columns with peer copies (wt_link_local / wt_step_group); the
+RCCL transport shares every line of this logic except the send/recv calls themselves."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(pkg, mask, chunks, tau, u0, dtype):
+    ny, nx = mask.shape
+    with pkg.Engine(nx, ny, dtype=dtype) as e:
+        e.set_mask(mask); e.init_equilibrium(u0)
+        for n in chunks:
+            e.step(n, tau, u0)
+        return e.read_f(), e.read_macro(), e.reduce_ranges(u0), e.forces()
+
+
+def _slabs(pkg, mask, nranks, halo, chunks, tau, u0, dtype):
+    ny, nx = mask.shape
+    es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    try:
+        assert sum(e.width for e in es) == nx and es[0].x0 == 0
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_mask(mask); e.init_equilibrium(u0)
+        for n in chunks:
+            pkg.Engine.step_group(es, n, tau, u0)
+        f = np.concatenate([e.read_f() for e in es], axis=2)
+        macro = [np.concatenate(parts, axis=1) for parts in zip(*[e.read_macro() for e in es])]
+        rr = [e.reduce_ranges(u0) for e in es]
+        ranges = (max(r[0] for r in rr), min(r[1] for r in rr), max(r[2] for r in rr))
+        ff = [e.forces() for e in es]
+        forces = (sum(x[0] for x in ff), sum(x[1] for x in ff), sum(x[2] for x in ff), sum(x[3] for x in ff))
+        return f, macro, ranges, forces
+    finally:
+        for e in es:
+            e.close()
+
+
+@pytest.mark.parametrize("nranks,halo,nx,ny,dtype", [
+    (2, 1, 512, 256, "float32"),
+    (2, 4, 512, 256, "float32"),
+    (4, 3, 512, 256, "float32"),
+    (3, 2, 333, 200, "float32"),      # uneven slabs, ragged tiles
+    (8, 16, 1024, 256, "float32"),    # the bench configuration's shape in miniature
+    (4, 5, 512, 128, "float64"),
+])
+def test_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, dtype):
+    mask = pkg.geometry.build_geometry(nx, ny, 7.0, None, "naca2412").mask     # body spans several slabs
+    chunks = [1, 2, halo, 2 * halo + 1, 23]
+    f0, m0, r0, F0 = _single(pkg, mask, chunks, 0.58, 0.06, dtype)
+    f1, m1, r1, F1 = _slabs(pkg, mask, nranks, halo, chunks, 0.58, 0.06, dtype)
+    assert bits_equal(f0, f1)
+    assert all(bits_equal(a, b) for a, b in zip(m0, m1))
+    assert r0 == r1
+    assert F0[2:] == F1[2:]
+    np.testing.assert_allclose(F0[:2], F1[:2], rtol=1e-12, atol=1e-13)
+
+
+def test_slab_restart_from_written_state(pkg):
+    """wt_write_f invalidates the ghosts: the next step must refresh them first."""
+    rng = np.random.default_rng(7)
+    nx, ny = 512, 256
+    mask = pkg.geometry.build_geometry(nx, ny, 3.0, None, "naca0012").mask
+    f_init = (0.1 + 0.01 * rng.random((9, ny, nx))).astype(np.float32)
+    with pkg.Engine(nx, ny) as e:
+        e.set_mask(mask); e.write_f(f_init); e.step(9, 0.58, 0.06)
+        want = e.read_f()
+    es = [pkg.Engine(nx, ny, rank=r, nranks=2, halo=2) for r in range(2)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_mask(mask); e.write_f(np.ascontiguousarray(f_init[:, :, e.x0:e.x0 + e.width]))
+        pkg.Engine.step_group(es, 9, 0.58, 0.06)
+        got = np.concatenate([e.read_f() for e in es], axis=2)
+    finally:
+        for e in es:
+            e.close()
+    assert bits_equal(want, got)
+
+
+def test_slab_argument_errors(pkg):
+    with pytest.raises(pkg.WTError):
+        pkg.Engine(64, 64, rank=0, nranks=2, halo=0)
+    with pytest.raises(pkg.WTError):
+        pkg.Engine(64, 64, rank=0, nranks=2, halo=40)         # wider than the slab
+    e = pkg.Engine(64, 64, rank=0, nranks=2, halo=2)
+    try:
+        e.set_mask(np.zeros((64, 64), np.uint8)); e.init_equilibrium(0.06)
+        with pytest.raises(pkg.WTError):
+            e.step(1, 0.58, 0.06)                              # no transport yet
+    finally:
+        e.close()
