@@ -75,14 +75,26 @@ static inline int classify_tiles(const uint8_t *mask, uint8_t *tiles, const Geom
 // --------------------------------------------------------------------------------------------
 template <typename T> struct Vec { T v[VecOf<T>::N]; };
 
-template <typename T>
+// 16-byte load.  NT: nontemporal ("streamed once") hint — the populations of the source lattice
+// are read exactly once per step, so they should not displace the freshly written lattice from
+// the Infinity Cache (measured: tools/kbench3, DESIGN.md "Memory system").
+// ALIGN4: the address is only element-aligned (the +-1 shifted rows).
+template <typename T, bool NT = false, bool ALIGN4 = false>
 __device__ __forceinline__ Vec<T> vload(const T *p)
 {
-    typedef typename VecOf<T>::type V;
-    const V x = *reinterpret_cast<const V *>(p);
+    constexpr int N = VecOf<T>::N;
+    typedef T VA __attribute__((ext_vector_type(N)));
+    typedef T VU __attribute__((ext_vector_type(N), aligned(sizeof(T))));
     Vec<T> r;
-    if constexpr (VecOf<T>::N == 4) { r.v[0] = x.x; r.v[1] = x.y; r.v[2] = x.z; r.v[3] = x.w; }
-    else { r.v[0] = x.x; r.v[1] = x.y; }
+    if constexpr (ALIGN4) {
+        const VU x = NT ? __builtin_nontemporal_load(reinterpret_cast<const VU *>(p)) : *reinterpret_cast<const VU *>(p);
+#pragma unroll
+        for (int v = 0; v < N; v++) r.v[v] = x[v];
+    } else {
+        const VA x = NT ? __builtin_nontemporal_load(reinterpret_cast<const VA *>(p)) : *reinterpret_cast<const VA *>(p);
+#pragma unroll
+        for (int v = 0; v < N; v++) r.v[v] = x[v];
+    }
     return r;
 }
 
@@ -132,17 +144,24 @@ __device__ __forceinline__ Vec<T> shift_from_above(const Vec<T> &r, const T *p, 
 // --------------------------------------------------------------------------------------------
 // the step kernel
 // --------------------------------------------------------------------------------------------
-template <typename T, bool EMIT>
+// LOADMODE bit 0: nontemporal loads of the source lattice; bit 1: the +-1 shifted rows are read
+// with element-aligned 16-B loads instead of aligned loads + lane shuffles.
+// rev: walk the tiles backwards.  Successive steps alternate the direction so that a step starts
+// by reading what the previous step wrote last — still resident in the 256 MB Infinity Cache.
+template <typename T, bool EMIT, int LOADMODE>
 __global__ __launch_bounds__(256) void k_step(const T *__restrict__ fs, T *__restrict__ fd, T *__restrict__ macro,
                                               const uint8_t *__restrict__ mask, const uint8_t *__restrict__ tiles,
-                                              int tiles_per_col, Geom g, int i_begin, int i_end, T tau, T U0)
+                                              int tiles_per_col, Geom g, int i_begin, int i_end, T tau, T U0, int rev)
 {
     constexpr int N = VecOf<T>::N;
     constexpr int TJ = 64 * N;
+    constexpr bool NT = (LOADMODE & 1) != 0;
+    constexpr bool UNALIGNED = (LOADMODE & 2) != 0;
     const int lane = threadIdx.x & 63;
-    const long tile_local = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long tile_local = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long ntiles = (long)(i_end - i_begin) * tiles_per_col;
     if (tile_local >= ntiles) return;
+    if (rev) tile_local = ntiles - 1 - tile_local;
     const int i = i_begin + (int)(tile_local / tiles_per_col);
     const int jt = (int)(tile_local % tiles_per_col);
     const int cls = __builtin_amdgcn_readfirstlane((int)tiles[(long)i * tiles_per_col + jt]);
@@ -169,21 +188,20 @@ __global__ __launch_bounds__(256) void k_step(const T *__restrict__ fs, T *__res
     if (cls == TILE_FAST) {
         Vec<T> fin[9];
         // ey = 0: aligned
-        fin[0] = vload<T>(s + 0 * P + c);
-        fin[1] = vload<T>(s + 1 * P + c - g.pitch);
-        fin[3] = vload<T>(s + 3 * P + c + g.pitch);
-        // ey = +1 -> source j-1
-        {
-            const T *p2 = s + 2 * P + c, *p5 = s + 5 * P + c - g.pitch, *p6 = s + 6 * P + c + g.pitch;
-            const Vec<T> r2 = vload<T>(p2), r5 = vload<T>(p5), r6 = vload<T>(p6);
+        fin[0] = vload<T, NT>(s + 0 * P + c);
+        fin[1] = vload<T, NT>(s + 1 * P + c - g.pitch);
+        fin[3] = vload<T, NT>(s + 3 * P + c + g.pitch);
+        const T *p2 = s + 2 * P + c, *p5 = s + 5 * P + c - g.pitch, *p6 = s + 6 * P + c + g.pitch;   // ey=+1: source j-1
+        const T *p4 = s + 4 * P + c, *p7 = s + 7 * P + c + g.pitch, *p8 = s + 8 * P + c - g.pitch;   // ey=-1: source j+1
+        if constexpr (UNALIGNED) {
+            fin[2] = vload<T, NT, true>(p2 - 1); fin[5] = vload<T, NT, true>(p5 - 1); fin[6] = vload<T, NT, true>(p6 - 1);
+            fin[4] = vload<T, NT, true>(p4 + 1); fin[7] = vload<T, NT, true>(p7 + 1); fin[8] = vload<T, NT, true>(p8 + 1);
+        } else {
+            const Vec<T> r2 = vload<T, NT>(p2), r5 = vload<T, NT>(p5), r6 = vload<T, NT>(p6);
+            const Vec<T> r4 = vload<T, NT>(p4), r7 = vload<T, NT>(p7), r8 = vload<T, NT>(p8);
             fin[2] = shift_from_below<T>(r2, p2, lane);
             fin[5] = shift_from_below<T>(r5, p5, lane);
             fin[6] = shift_from_below<T>(r6, p6, lane);
-        }
-        // ey = -1 -> source j+1
-        {
-            const T *p4 = s + 4 * P + c, *p7 = s + 7 * P + c + g.pitch, *p8 = s + 8 * P + c - g.pitch;
-            const Vec<T> r4 = vload<T>(p4), r7 = vload<T>(p7), r8 = vload<T>(p8);
             fin[4] = shift_from_above<T>(r4, p4, lane);
             fin[7] = shift_from_above<T>(r7, p7, lane);
             fin[8] = shift_from_above<T>(r8, p8, lane);
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(256) void k_step(const T *__restrict__ fs, T *__res
         }
     } else if (cls == TILE_SOLID) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) out[k] = vload<T>(s + opp_of(k) * P + c);
+        for (int k = 0; k < 9; k++) out[k] = vload<T, NT>(s + opp_of(k) * P + c);
 #pragma unroll
         for (int v = 0; v < N; v++) { mrho.v[v] = T(1.0); mux.v[v] = T(0.0); muy.v[v] = T(0.0); }
     } else if (cls == TILE_INLET) {
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(256) void k_step(const T *__restrict__ fs, T *__res
         for (int v = 0; v < N; v++) { mrho.v[v] = T(1.0); mux.v[v] = U0; muy.v[v] = T(0.0); }
     } else {   // TILE_OUTLET: copy the un-streamed populations of column i-1 (html:301-312)
 #pragma unroll
-        for (int k = 0; k < 9; k++) out[k] = vload<T>(s + k * P + c - g.pitch);
+        for (int k = 0; k < 9; k++) out[k] = vload<T, NT>(s + k * P + c - g.pitch);
 #pragma unroll
         for (int v = 0; v < N; v++) {
             const T q0 = out[0].v[v], q1 = out[1].v[v], q2 = out[2].v[v], q3 = out[3].v[v], q4 = out[4].v[v],
@@ -241,16 +259,19 @@ __global__ __launch_bounds__(256) void k_step(const T *__restrict__ fs, T *__res
 }
 
 // launch over local columns [i_begin, i_end)
-template <typename T>
+#ifndef WT_LOADMODE
+#define WT_LOADMODE 3
+#endif
+template <typename T, int LOADMODE = WT_LOADMODE>
 static inline int step_columns(const T *fs, T *fd, T *macro, const uint8_t *mask, const uint8_t *tiles, int tiles_per_col,
-                               const Geom &g, int i_begin, int i_end, T tau, T U0, bool emit, hipStream_t st)
+                               const Geom &g, int i_begin, int i_end, T tau, T U0, bool emit, int rev, hipStream_t st)
 {
     const long ntiles = (long)(i_end - i_begin) * tiles_per_col;
     const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
     if (emit)
-        hipLaunchKernelGGL((k_step<T, true>), grid, block, 0, st, fs, fd, macro, mask, tiles, tiles_per_col, g, i_begin, i_end, tau, U0);
+        hipLaunchKernelGGL((k_step<T, true, LOADMODE>), grid, block, 0, st, fs, fd, macro, mask, tiles, tiles_per_col, g, i_begin, i_end, tau, U0, rev);
     else
-        hipLaunchKernelGGL((k_step<T, false>), grid, block, 0, st, fs, fd, macro, mask, tiles, tiles_per_col, g, i_begin, i_end, tau, U0);
+        hipLaunchKernelGGL((k_step<T, false, LOADMODE>), grid, block, 0, st, fs, fd, macro, mask, tiles, tiles_per_col, g, i_begin, i_end, tau, U0, rev);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

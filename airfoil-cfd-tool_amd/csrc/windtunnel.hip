@@ -149,7 +149,13 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     g.gi0 = h->x0 - h->gl;
     g.nx_g = nx_g;
     g.pitch = ((long)ny + 255) / 256 * 256;
-    g.plane = (long)(g.nxl + 2) * g.pitch;
+    {
+        // Plane stride: the nine population planes are walked in lock-step, so a stride that is a
+        // multiple of a large power of two would park all 18 streams on the same HBM channels.
+        // Round the plane to 4 KiB and add an odd multiple of 1 KiB (measured: tools/kbench3).
+        const long plane_bytes = ((long)(g.nxl + 2) * g.pitch * (long)h->esz + 4095) / 4096 * 4096 + 17408;
+        g.plane = plane_bytes / (long)h->esz;
+    }
     h->tiles_per_col = (int)(g.pitch / tile_j_of(h->esz));
 
     auto cleanup = [&](int rc) { wt_destroy(h); return rc; };
@@ -338,7 +344,7 @@ static int launch_step(wt_handle *h, int i_begin, int i_end, double tau, double 
 {
     if (i_end <= i_begin) return WT_OK;
     return step_columns<T>(fptr<T>(h, h->cur), fptr<T>(h, 1 - h->cur), reinterpret_cast<T *>(h->macro), h->mask,
-                           h->tiles, h->tiles_per_col, h->g, i_begin, i_end, (T)tau, (T)u0, emit, st);
+                           h->tiles, h->tiles_per_col, h->g, i_begin, i_end, (T)tau, (T)u0, emit, (int)(h->steps_done & 1), st);
 }
 
 static int launch_step_any(wt_handle *h, int i_begin, int i_end, double tau, double u0, bool emit, hipStream_t st)
