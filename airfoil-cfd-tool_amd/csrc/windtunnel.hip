@@ -741,6 +741,47 @@ extern "C" int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, in
     return WT_OK;
 }
 
+// Vorticity (html:411-417) needs uy of the columns left and right of the slab: fetch the
+// neighbours' edge columns of the macro uy plane into this slab's innermost ghost columns.
+// TR_RCCL: collective — every rank must be inside wt_field(WT_FIELD_VORT) together.
+static int refresh_macro_ghosts(wt_handle *h)
+{
+    if (h->transport == TR_NONE) return fail(WT_ERR_STATE, "slab handle has no transport");
+    const Geom &g = h->g;
+    const size_t mp = (size_t)g.nxl * g.pitch;
+    auto uy_col = [&](wt_handle *q, int i) { return reinterpret_cast<char *>(q->macro) + (2 * (size_t)q->g.nxl * q->g.pitch + (size_t)i * q->g.pitch) * q->esz; };
+    (void)mp;
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    if (h->transport == TR_RCCL) {
+        const ncclDataType_t dt = h->dtype == WT_F32 ? ncclFloat32 : ncclFloat64;
+        const size_t count = (size_t)g.pitch;
+        NCCL_TRY(ncclGroupStart());
+        if (h->gl) {
+            NCCL_TRY(ncclSend(uy_col(h, h->gl), count, dt, h->rank - 1, h->comm, h->s_comm));
+            NCCL_TRY(ncclRecv(uy_col(h, h->gl - 1), count, dt, h->rank - 1, h->comm, h->s_comm));
+        }
+        if (h->gr) {
+            NCCL_TRY(ncclSend(uy_col(h, h->gl + h->width - 1), count, dt, h->rank + 1, h->comm, h->s_comm));
+            NCCL_TRY(ncclRecv(uy_col(h, h->gl + h->width), count, dt, h->rank + 1, h->comm, h->s_comm));
+        }
+        NCCL_TRY(ncclGroupEnd());
+    } else {
+        const size_t bytes = (size_t)g.pitch * h->esz;
+        if (h->gl) {
+            wt_handle *p = h->peer_l;
+            HIP_TRY(hipSetDevice(p->device)); HIP_TRY(hipStreamSynchronize(p->s_compute)); HIP_TRY(hipSetDevice(h->device));
+            HIP_TRY(hipMemcpyPeerAsync(uy_col(h, h->gl - 1), h->device, uy_col(p, p->gl + p->width - 1), p->device, bytes, h->s_comm));
+        }
+        if (h->gr) {
+            wt_handle *p = h->peer_r;
+            HIP_TRY(hipSetDevice(p->device)); HIP_TRY(hipStreamSynchronize(p->s_compute)); HIP_TRY(hipSetDevice(h->device));
+            HIP_TRY(hipMemcpyPeerAsync(uy_col(h, h->gl + h->width), h->device, uy_col(p, p->gl), p->device, bytes, h->s_comm));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(h->s_comm));
+    return WT_OK;
+}
+
 template <typename T>
 static int field_impl(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max, double vs, void *out)
 {
@@ -765,9 +806,8 @@ extern "C" int wt_field(wt_handle *h, int mode, double u0, double max_s, double 
     if (!t_out) return fail(WT_ERR_ARG, "t_out is null");
     if (mode < 0 || mode > 2) return fail(WT_ERR_ARG, "mode must be 0 (speed), 1 (cp) or 2 (vort)");
     if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
-    if (mode == WT_FIELD_VORT && h->nranks > 1)
-        return fail(WT_ERR_STATE, "vorticity on a slab handle needs macro ghost columns (not implemented yet)");
     HIP_TRY(hipSetDevice(h->device));
+    if (mode == WT_FIELD_VORT && h->nranks > 1) WT_TRY(refresh_macro_ghosts(h));
     return h->dtype == WT_F32 ? field_impl<float>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, t_out)
                               : field_impl<double>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, t_out);
 }

@@ -1,0 +1,74 @@
+"""One rank of the world_size-N gloo test (spawned by tests/test_distributed_gloo.py)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    rank, world, port, halo = (int(v) for v in sys.argv[1:5])
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lbm_numpy as oracle
+    from _slab_standin import OracleSlabEngine
+    from airfoil_cfd_tool_amd.distributed import SlabWindTunnel, slab_bounds
+
+    nx, ny = 96, 48
+    wt = SlabWindTunnel(shape="naca4412", nx=nx, ny=ny, aoa_deg=9.0, halo=halo, engine_factory=OracleSlabEngine)
+    assert wt.bounds == slab_bounds(nx, world) and sum(w for _, w in wt.bounds) == nx
+    frames = 7
+    for _ in range(frames):
+        wt.frame()
+    wt.aoa_deg = 15.0                      # AoA slider on every rank
+    wt.set_flow_speed(0.07)
+    wt.sim_step(5)
+    wt.update_fields_from_macro()
+    wt.compute_forces()
+    macro = wt.read_macro()
+    f = wt.read_f()
+    t_speed = wt.render_field("speed")
+    ok = True
+    if rank == 0:
+        import airfoil_cfd_tool_amd.geometry as geo
+        m1 = geo.build_geometry(nx, ny, 9.0, None, "naca4412").mask
+        m2 = geo.build_geometry(nx, ny, 15.0, None, "naca4412").mask
+        fr = None
+        prev = (0.6, -1.0, 1.0)
+        st = oracle.ForceState()
+        for k in range(1, frames + 1):
+            fr, mac = oracle.run(m1, 4, 0.58, 0.06, np.float32, f=fr)
+            prev = oracle.ranges_from_macro(*mac, m1, 0.06, prev)
+            if k % 3 == 0:
+                st.update(*oracle.compute_forces_raw(mac[0], mac[1], m1), 0.06, nx)
+        fr, mac = oracle.run(m2, 5, 0.58, 0.07, np.float32, f=fr)
+        prev = oracle.ranges_from_macro(*mac, m2, 0.07, prev)
+        st.update(*oracle.compute_forces_raw(mac[0], mac[1], m2), 0.07, nx)
+        ok &= np.array_equal(f, fr) and all(np.array_equal(a, b) for a, b in zip(macro, mac))
+        ok &= np.allclose([wt.max_s, wt.cp_min, wt.cp_max], prev, rtol=1e-13, atol=0)
+        ok &= np.allclose([wt.cl_smooth, wt.cd_smooth, wt.sep_frac], [st.cl, st.cd, st.sep], rtol=1e-11, atol=1e-13)
+        ref_t = oracle.field_scalar(0, *mac, m2, 0.07, *prev)
+        ok &= np.array_equal(np.nan_to_num(t_speed), np.nan_to_num(ref_t))
+        ok &= wt.stats().separation == oracle.stall_label(st.sep)
+        print("rank0 checks", "PASS" if ok else "FAIL", flush=True)
+    else:
+        ok &= macro is None and f is None and t_speed is None
+    # every rank must hold the same combined reductions
+    import torch
+    t = torch.tensor([wt.max_s, wt.cp_min, wt.cp_max, wt.cl_smooth, wt.cd_smooth, wt.sep_frac], dtype=torch.float64)
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    ok &= bool(torch.equal(lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -95,3 +95,25 @@ def test_slab_argument_errors(pkg):
             e.step(1, 0.58, 0.06)                              # no transport yet
     finally:
         e.close()
+
+
+def test_slab_fields_equal_single_lattice(pkg):
+    """wt_field on slabs (vorticity pulls the neighbours' uy edge columns) vs the single lattice."""
+    nx, ny = 512, 256
+    mask = pkg.geometry.build_geometry(nx, ny, 12.0, None, "naca4412").mask
+    with pkg.Engine(nx, ny) as e:
+        e.set_mask(mask); e.init_equilibrium(0.06); e.step(90, 0.58, 0.06)
+        rng = e.reduce_ranges(0.06)
+        want = [e.field(m, 0.06, rng[0], rng[1], rng[2], 0.06) for m in range(3)]
+    es = [pkg.Engine(nx, ny, rank=r, nranks=4, halo=3) for r in range(4)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        pkg.Engine.step_group(es, 90, 0.58, 0.06)
+        for m in range(3):
+            got = np.concatenate([e.field(m, 0.06, rng[0], rng[1], rng[2], 0.06) for e in es], axis=1)
+            assert bits_equal(np.nan_to_num(got), np.nan_to_num(want[m])) and np.array_equal(np.isnan(got), np.isnan(want[m]))
+    finally:
+        for e in es:
+            e.close()
