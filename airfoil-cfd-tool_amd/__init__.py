@@ -4,9 +4,10 @@
 Import as ``airfoil_cfd_tool_amd`` (the directory name carries a hyphen; the
 sibling ``airfoil_cfd_tool_amd/`` package forwards here).
 """
-from . import geometry  # noqa: F401
+from . import geometry, datfile  # noqa: F401
+from .datfile import DatParseError, load_dat, parse_dat_file, detect_and_merge_sections  # noqa: F401
 from ._capi import Engine, WTError, load_library, LIB_PATH  # noqa: F401
 from .windtunnel import (WindTunnel, build_lbm_component, Stats, stall_label, tau_from_reynolds,  # noqa: F401
-                         reynolds, chord_cells, FIELD_MODES, TAU_DEFAULT, U0_DEFAULT, VORT_SCALE, STEPS_PER_FRAME)
+                         reynolds, chord_cells, write_png, FIELD_MODES, TAU_DEFAULT, U0_DEFAULT, VORT_SCALE, STEPS_PER_FRAME)
 
 __all__ = ["WindTunnel", "build_lbm_component", "Engine", "WTError", "geometry", "load_library"]

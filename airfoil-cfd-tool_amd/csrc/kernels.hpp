@@ -295,4 +295,78 @@ __global__ void k_field(const T *__restrict__ macro, const uint8_t *__restrict__
     }
 }
 
+
+// --------------------------------------------------------------------------------------
+// RENDER_FS colour maps (html:371-393) and solid colour (html:397), evaluated in T like the
+// shader (mix(a,b,u) = a*(1-u)+b*u, stops divided by 255.0), then quantised to RGBA8 the way a
+// GL framebuffer does (round to nearest).
+// --------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void lerp_stops(T t, const unsigned char (*stops)[3], int nseg, T (&rgb)[3])
+{
+    t = t < T(0.0) ? T(0.0) : t;            // clamp(t,0,1) = min(max(t,0),1)
+    t = T(1.0) < t ? T(1.0) : t;
+    const T f = t * T(nseg);
+    int i = (int)floor((double)f);
+    if (i > nseg - 1) i = nseg - 1;
+    if (i < 0) i = 0;
+    const T u = f - T(i);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const T a = T(stops[i][c]) / T(255.0), b = T(stops[i + 1][c]) / T(255.0);
+        rgb[c] = a * (T(1.0) - u) + b * u;
+    }
+}
+
+__device__ const unsigned char kSpeedStops[10][3] = {{5, 5, 20}, {0, 20, 120}, {0, 60, 200}, {0, 140, 220}, {0, 220, 220},
+                                                     {0, 210, 140}, {80, 200, 0}, {220, 210, 0}, {255, 120, 0}, {220, 20, 0}};
+__device__ const unsigned char kCpStops[8][3] = {{20, 50, 160}, {40, 110, 210}, {100, 175, 235}, {190, 220, 245},
+                                                 {248, 248, 248}, {248, 214, 140}, {240, 150, 60}, {205, 50, 25}};
+
+template <typename T>
+__device__ __forceinline__ void colour_of(int mode, T t, T (&rgb)[3])
+{
+    if (mode == 0) { lerp_stops<T>(t, kSpeedStops, 9, rgb); return; }
+    if (mode == 1) { lerp_stops<T>(t, kCpStops, 7, rgb); return; }
+    t = t < T(-1.0) ? T(-1.0) : t;          // vortColor, html:389-393
+    t = T(1.0) < t ? T(1.0) : t;
+    const T base[3] = {T(0.06), T(0.07), T(0.11)};
+    const T neg[3] = {T(0.15), T(0.5), T(0.98)}, pos[3] = {T(0.98), T(0.28), T(0.18)};
+    const bool isneg = t < T(0.0);
+    const T a = isneg ? -t : t;
+#pragma unroll
+    for (int c = 0; c < 3; c++) rgb[c] = base[c] * (T(1.0) - a) + (isneg ? neg[c] : pos[c]) * a;
+}
+
+__device__ __forceinline__ unsigned char to_unorm8(double c)
+{
+    c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+    return (unsigned char)(int)(c * 255.0 + 0.5);
+}
+
+template <typename T>
+__global__ void k_render(const T *__restrict__ macro, const uint8_t *__restrict__ mask, Geom g,
+                         int i_own0, int W, FieldParams<T> fp, uchar4 *__restrict__ out)
+{
+    __shared__ uchar4 tile[32][33];
+    const uint8_t *m = mask + g.pitch;
+    const int bj = blockIdx.x * 32, bx = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int x = bx + r, j = bj + threadIdx.x;
+        if (x < W && j < g.ny) {
+            const int i = i_own0 + x;
+            const long c = (long)i * g.pitch + j;
+            T rgb[3];
+            if (m[c]) { rgb[0] = T(0.039); rgb[1] = T(0.043); rgb[2] = T(0.078); }
+            else colour_of<T>(fp.mode, field_value<T>(macro, g, i, j, fp), rgb);
+            tile[r][threadIdx.x] = make_uchar4(to_unorm8((double)rgb[0]), to_unorm8((double)rgb[1]), to_unorm8((double)rgb[2]), 255);
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+        const int j = bj + r, x = bx + threadIdx.x;
+        if (x < W && j < g.ny) out[(long)j * W + x] = tile[threadIdx.x][r];
+    }
+}
+
 }  // namespace wt

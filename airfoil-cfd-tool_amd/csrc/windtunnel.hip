@@ -812,10 +812,32 @@ extern "C" int wt_field(wt_handle *h, int mode, double u0, double max_s, double 
                               : field_impl<double>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, t_out);
 }
 
+template <typename T>
+static int render_impl(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max, double vs, uint8_t *out)
+{
+    const Geom &g = h->g;
+    const size_t bytes = (size_t)h->width * g.ny * 4;
+    WT_TRY(ensure_stage(h, bytes));
+    FieldParams<T> fp;
+    fp.U0 = (T)u0; fp.maxS = (T)max_s; fp.cpMin = (T)cp_min; fp.cpMax = (T)cp_max; fp.vortScale = (T)vs; fp.mode = mode;
+    dim3 blk(32, 8), grd((g.ny + 31) / 32, (h->width + 31) / 32);
+    hipLaunchKernelGGL(k_render<T>, grd, blk, 0, h->s_compute, reinterpret_cast<const T *>(h->macro), h->mask, g, h->gl,
+                       h->width, fp, reinterpret_cast<uchar4 *>(h->stage));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    return WT_OK;
+}
+
 extern "C" int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
                               double vort_scale, uint8_t *rgba_out)
 {
-    (void)mode; (void)u0; (void)max_s; (void)cp_min; (void)cp_max; (void)vort_scale; (void)rgba_out;
     WT_TRY(check_handle(h));
-    return fail(WT_ERR_STATE, "wt_render_rgba: colour-map renderer not built yet (SURVEY §8 f2)");
+    if (!rgba_out) return fail(WT_ERR_ARG, "rgba_out is null");
+    if (mode < 0 || mode > 2) return fail(WT_ERR_ARG, "mode must be 0 (speed), 1 (cp) or 2 (vort)");
+    if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    HIP_TRY(hipSetDevice(h->device));
+    if (mode == WT_FIELD_VORT && h->nranks > 1) WT_TRY(refresh_macro_ghosts(h));
+    return h->dtype == WT_F32 ? render_impl<float>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, rgba_out)
+                              : render_impl<double>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, rgba_out);
 }

@@ -106,8 +106,20 @@ class WindTunnel:
         self.steps = 0
         self.geometry: Optional[geo.Geometry] = None
         self.macro = None
+        self.parser_fixes: list = []
         self.init_sim(self.u0)                                   # html:502-504
         self.apply_geometry(aoa_deg)                             # html:969-970
+
+    @classmethod
+    def from_dat(cls, dat_path: str, name: Optional[str] = None, **kwargs) -> "WindTunnel":
+        """The page's `.dat` upload: parse/repair the file like the back end (main.py:543-608 ->
+        datfile.load_dat) and feed `coords_after` to the tunnel like AA.py:1413-1416."""
+        import os
+        from .datfile import load_dat
+        coords, fixes = load_dat(dat_path)
+        wt = cls(coords, name or os.path.splitext(os.path.basename(dat_path))[0], **kwargs)
+        wt.parser_fixes = fixes
+        return wt
 
     # ---- the component's runtime, under its JS names -------------------------------
     def init_sim(self, u0: float) -> None:
@@ -182,6 +194,19 @@ class WindTunnel:
                                  self.cp_min if cp_min is None else cp_min,
                                  self.cp_max if cp_max is None else cp_max, VORT_SCALE)
 
+    def render_rgba(self, field: Optional[str] = None) -> np.ndarray:
+        """renderField through RENDER_FS's colour maps (html:371-397): RGBA8 [NY][NX][4], row 0 = bottom,
+        using the current (previous frame's) ranges like html:909."""
+        mode = FIELD_MODES[field or self.field]
+        return self.engine.render_rgba(mode, self.u0, self.max_s, self.cp_min, self.cp_max, VORT_SCALE)
+
+    def save_png(self, path: Optional[str] = None, field: Optional[str] = None) -> str:
+        """The field image as a PNG named like the page's download (html:980-1000).  Only the
+        lattice field is drawn (the page's particles/labels are browser-side canvas work)."""
+        path = path or self.png_name()
+        write_png(path, self.render_rgba(field)[::-1])          # PNG rows run top to bottom
+        return path
+
     def frame(self, render: bool = True):
         """One pass of frame() (html:902-930) without the browser-only parts:
         4 steps, field with the PREVIOUS frame's ranges, range update, forces
@@ -223,6 +248,28 @@ class WindTunnel:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def write_png(path: str, rgba: np.ndarray) -> None:
+    """Minimal RGBA8 PNG encoder (zlib only; the image has no PIL dependency)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("rgba must be [H][W][4] uint8")
+    h, w, _ = a.shape
+    raw = np.empty((h, 1 + 4 * w), dtype=np.uint8)
+    raw[:, 0] = 0                                                # filter type 0 on every scanline
+    raw[:, 1:] = a.reshape(h, 4 * w)
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n")
+        fh.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)))
+        fh.write(chunk(b"IDAT", zlib.compress(raw.tobytes(), 6)))
+        fh.write(chunk(b"IEND", b""))
 
 
 def build_lbm_component(coords_after, airfoil_name: str = "", **kwargs) -> WindTunnel:

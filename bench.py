@@ -102,6 +102,8 @@ def main():
     import torch.distributed as dist
     import airfoil_cfd_tool_amd as wtpkg
 
+    if os.environ.get("WT_BENCH_FORCE_DEVICE") is not None:      # plumbing tests on a 1-GPU box only
+        local_rank = int(os.environ["WT_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:

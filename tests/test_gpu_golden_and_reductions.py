@@ -125,3 +125,58 @@ def test_build_lbm_component_with_user_coords(pkg, oracle_c):
         assert wt.png_name() == "NACA_0012_(UIUC)_alpha4.0deg_lbm.png"
         f_ref, _ = oracle_c.run(wt.geometry.mask, 40, 0.58, 0.06, np.float32)
         assert bits_equal(f, f_ref)
+
+
+def test_render_rgba_vs_reference_render_shader(pkg, tmp_path):
+    """wt_render_rgba against RENDER_FS (html:362-422) run by Node on the golden macro field: the
+    shader's float colours quantised like a GL RGBA8 framebuffer (round to nearest)."""
+    g = np.load(os.path.join(GOLDEN, "run_64x32_naca0012_a0_f32.npz"))
+    want = np.floor(g["render_rgb"].astype(np.float64) * 255.0 + 0.5).astype(np.uint8)     # [mode][ny][nx][3]
+    with _drive(pkg, g) as wt:
+        wt.update_fields_from_macro()
+        for mode, name in enumerate(("speed", "cp", "vort")):
+            img = wt.render_rgba(name)
+            assert img.shape == (32, 64, 4) and img.dtype == np.uint8 and (img[..., 3] == 255).all()
+            assert np.array_equal(img[..., :3], want[mode]), name
+        path = wt.save_png(str(tmp_path / "x.png"), "speed")
+        data = open(path, "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n" and b"IHDR" in data[:32] and data[-8:-4] == b"IEND"
+        import struct
+        assert struct.unpack(">II", data[16:24]) == (64, 32)
+
+
+def test_render_rgba_fp64_and_slabs(pkg):
+    nx, ny = 512, 256
+    mask = pkg.geometry.build_geometry(nx, ny, 10.0, None, "naca2412").mask
+    with pkg.Engine(nx, ny, dtype="float64") as e:
+        e.set_mask(mask); e.init_equilibrium(0.06); e.step(60, 0.58, 0.06)
+        rng = e.reduce_ranges(0.06)
+        want = [e.render_rgba(m, 0.06, rng[0], rng[1], rng[2], 0.06) for m in range(3)]
+        assert (want[0][mask != 0][:, :3] == np.array([10, 11, 20], np.uint8)).all()      # solid colour, html:397
+    es = [pkg.Engine(nx, ny, dtype="float64", rank=r, nranks=2, halo=2) for r in range(2)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        pkg.Engine.step_group(es, 60, 0.58, 0.06)
+        for m in range(3):
+            got = np.concatenate([e.render_rgba(m, 0.06, rng[0], rng[1], rng[2], 0.06) for e in es], axis=1)
+            assert np.array_equal(got, want[m])
+    finally:
+        for e in es:
+            e.close()
+
+
+def test_from_dat_upload_path(pkg, oracle_c, tmp_path):
+    """.dat upload -> parser repairs -> coords_after -> tunnel (main.py:543-608 -> AA.py:1413 -> html:561)."""
+    import json
+    with open(os.path.join(GOLDEN, "datfile_cases.json"), encoding="utf-8") as fh:
+        case = next(c for c in json.load(fh)["cases"] if c["name"] == "lednicer_counts_header")
+    p = tmp_path / "my foil.dat"
+    p.write_text(case["text"])
+    with pkg.WindTunnel.from_dat(str(p), nx=256, ny=128, aoa_deg=5.0) as wt:
+        assert wt.parser_fixes == case["fixes"] and wt.name == "my foil"
+        assert wt.png_name() == "my_foil_alpha5.0deg_lbm.png"
+        wt.sim_step(50)
+        f_ref, _ = oracle_c.run(wt.geometry.mask, 50, 0.58, 0.06, np.float32)
+        assert bits_equal(wt.read_f(), f_ref)
