@@ -10,4 +10,6 @@ from ._capi import Engine, WTError, load_library, LIB_PATH  # noqa: F401
 from .windtunnel import (WindTunnel, build_lbm_component, Stats, stall_label, tau_from_reynolds,  # noqa: F401
                          reynolds, chord_cells, write_png, FIELD_MODES, TAU_DEFAULT, U0_DEFAULT, VORT_SCALE, STEPS_PER_FRAME)
 
+from .tracers import Tracers  # noqa: F401
+
 __all__ = ["WindTunnel", "build_lbm_component", "Engine", "WTError", "geometry", "load_library"]

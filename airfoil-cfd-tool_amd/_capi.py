@@ -24,7 +24,7 @@ EXPORTS = (
     "wt_create", "wt_create_slab", "wt_destroy", "wt_get_info", "wt_last_error", "wt_version",
     "wt_comm_unique_id", "wt_comm_init_rank", "wt_link_local", "wt_step_group",
     "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_read_f", "wt_write_f",
-    "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_field", "wt_render_rgba", "wt_sync",
+    "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_field", "wt_render_rgba", "wt_advect_tracers", "wt_sync",
 )
 
 
@@ -85,6 +85,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "wt_forces": ([H, POINTER(c_double), POINTER(c_double), POINTER(c_int64), POINTER(c_int64)], c_int),
         "wt_field": ([H, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p], c_int),
         "wt_render_rgba": ([H, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p], c_int),
+        "wt_advect_tracers": ([H, c_int, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_double,
+                               c_void_p, c_void_p, c_void_p, c_void_p], c_int),
         "wt_sync": ([H], c_int),
     }
     for name, (argtypes, restype) in sig.items():
@@ -229,6 +231,21 @@ class Engine:
         _check(self._lib.wt_render_rgba(self._h, int(mode), float(u0), float(max_s), float(cp_min), float(cp_max),
                                         float(vort_scale), out.ctypes.data_as(c_void_p)))
         return out
+
+    def advect_tracers(self, x: np.ndarray, y: np.ndarray, dt_frame: float, u0: float, window):
+        """advect() for arrays of particles; returns (x_new, y_new, speed, ok)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if x.shape != y.shape or x.ndim != 1:
+            raise ValueError("x and y must be 1-D arrays of equal length")
+        n = x.size
+        xn, yn, sp = np.empty(n), np.empty(n), np.empty(n)
+        ok = np.empty(n, dtype=np.uint8)
+        dx0, dx1, dy0, dy1 = (float(v) for v in window)
+        _check(self._lib.wt_advect_tracers(self._h, n, x.ctypes.data_as(c_void_p), y.ctypes.data_as(c_void_p), float(dt_frame),
+                                           float(u0), dx0, dx1, dy0, dy1, xn.ctypes.data_as(c_void_p),
+                                           yn.ctypes.data_as(c_void_p), sp.ctypes.data_as(c_void_p), ok.ctypes.data_as(c_void_p)))
+        return xn, yn, sp, ok.astype(bool)
 
     def sync(self) -> None:
         _check(self._lib.wt_sync(self._h))

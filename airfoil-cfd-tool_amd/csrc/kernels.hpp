@@ -369,4 +369,63 @@ __global__ void k_render(const T *__restrict__ macro, const uint8_t *__restrict_
     }
 }
 
+
+// --------------------------------------------------------------------------------------
+// tracer particles: sampleScalar / sampleUV (html:616-639) and advect (html:758-771).
+// JS doubles on top of Ufield/Vfield = Float32Array(ux/U0, uy/U0) (html:603-604), solids excluded.
+// --------------------------------------------------------------------------------------
+struct Window { double dx0, dx1, dy0, dy1; };
+
+template <typename T>
+__device__ __forceinline__ bool sample_uv(const T *__restrict__ macro, const uint8_t *__restrict__ m, const Geom &g, int i_own0,
+                                          double U0, const Window &w, double wx, double wy, double &u, double &v)
+{
+    if (wx < w.dx0 || wx > w.dx1 || wy < w.dy0 || wy > w.dy1) return false;
+    const int NX = g.nx_g, NY = g.ny;
+    const double fx = (wx - w.dx0) / (w.dx1 - w.dx0) * NX - 0.5;
+    const double fy = (wy - w.dy0) / (w.dy1 - w.dy0) * NY - 0.5;
+    int ix = (int)floor(fx), iy = (int)floor(fy);
+    ix = ix > NX - 2 ? NX - 2 : ix; ix = ix < 0 ? 0 : ix;
+    iy = iy > NY - 2 ? NY - 2 : iy; iy = iy < 0 ? 0 : iy;
+    const double tx = fx - ix, ty = fy - iy;
+    const double ws[4] = {(1 - tx) * (1 - ty), tx * (1 - ty), (1 - tx) * ty, tx * ty};
+    const int cx[4] = {ix, ix + 1, ix, ix + 1}, cy[4] = {iy, iy, iy + 1, iy + 1};
+    const long mp = (long)g.nxl * g.pitch;
+    double su = 0, wu = 0, sv = 0, wv = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long c = (long)(i_own0 + cx[k]) * g.pitch + cy[k];
+        if (m[c]) continue;
+        const double U = (double)(float)((double)macro[mp + c] / U0);
+        const double V = (double)(float)((double)macro[2 * mp + c] / U0);
+        if (isfinite(U)) { su += U * ws[k]; wu += ws[k]; }
+        if (isfinite(V)) { sv += V * ws[k]; wv += ws[k]; }
+    }
+    if (!(wu > 0) || !(wv > 0)) return false;
+    u = su / wu; v = sv / wv;
+    return true;
+}
+
+template <typename T>
+__global__ void k_advect(const T *__restrict__ macro, const uint8_t *__restrict__ mask, Geom g, int i_own0, double U0, Window w,
+                         double dt_frame, int n, const double *__restrict__ px, const double *__restrict__ py,
+                         double *__restrict__ ox, double *__restrict__ oy, double *__restrict__ ospeed, unsigned char *__restrict__ ok)
+{
+    const uint8_t *m = mask + g.pitch;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const double x = px[t], y = py[t];
+        double u1, v1;
+        if (!sample_uv<T>(macro, m, g, i_own0, U0, w, x, y, u1, v1)) { ok[t] = 0; ox[t] = x; oy[t] = y; ospeed[t] = 0.0; continue; }
+        const double kBase = 0.00105 * dt_frame;
+        const double speed1 = hypot(u1, v1);
+        double dtEff = kBase;
+        const double maxDisp = 0.05;
+        if (speed1 * dtEff > maxDisp) dtEff = maxDisp / fmax(speed1, 1e-6);
+        const double midx = x + u1 * dtEff * 0.5, midy = y + v1 * dtEff * 0.5;
+        double u2, v2;
+        if (!sample_uv<T>(macro, m, g, i_own0, U0, w, midx, midy, u2, v2)) { u2 = u1; v2 = v1; }
+        ox[t] = x + u2 * dtEff; oy[t] = y + v2 * dtEff; ospeed[t] = hypot(u2, v2); ok[t] = 1;
+    }
+}
+
 }  // namespace wt

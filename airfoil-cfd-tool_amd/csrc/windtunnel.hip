@@ -841,3 +841,41 @@ extern "C" int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, d
     return h->dtype == WT_F32 ? render_impl<float>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, rgba_out)
                               : render_impl<double>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, rgba_out);
 }
+
+// ------------------------------------------------------------------------------------------
+// tracers
+// ------------------------------------------------------------------------------------------
+extern "C" int wt_advect_tracers(wt_handle *h, int n, const double *x, const double *y, double dt_frame, double u0,
+                                 double dx0, double dx1, double dy0, double dy1,
+                                 double *x_new, double *y_new, double *speed, uint8_t *ok)
+{
+    WT_TRY(check_handle(h));
+    if (n < 0 || (n > 0 && (!x || !y || !x_new || !y_new || !speed || !ok))) return fail(WT_ERR_ARG, "bad tracer arrays");
+    if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (h->nranks > 1) return fail(WT_ERR_STATE, "tracers need the whole lattice on one handle");
+    if (!(dx1 > dx0) || !(dy1 > dy0) || !(u0 != 0.0)) return fail(WT_ERR_ARG, "bad window or u0");
+    if (n == 0) return WT_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t nd = (size_t)n * sizeof(double);
+    WT_TRY(ensure_stage(h, 5 * nd + (size_t)n + 64));
+    char *base = reinterpret_cast<char *>(h->stage);
+    double *dx = reinterpret_cast<double *>(base), *dy = dx + n, *ox = dy + n, *oy = ox + n, *os = oy + n;
+    unsigned char *dok = reinterpret_cast<unsigned char *>(os + n);
+    HIP_TRY(hipMemcpyAsync(dx, x, nd, hipMemcpyHostToDevice, h->s_compute));
+    HIP_TRY(hipMemcpyAsync(dy, y, nd, hipMemcpyHostToDevice, h->s_compute));
+    const Window w{dx0, dx1, dy0, dy1};
+    const int nb = (n + 255) / 256;
+    if (h->dtype == WT_F32)
+        hipLaunchKernelGGL(k_advect<float>, dim3(nb), dim3(256), 0, h->s_compute, (const float *)h->macro, h->mask, h->g, h->gl, u0, w,
+                           dt_frame, n, dx, dy, ox, oy, os, dok);
+    else
+        hipLaunchKernelGGL(k_advect<double>, dim3(nb), dim3(256), 0, h->s_compute, (const double *)h->macro, h->mask, h->g, h->gl, u0, w,
+                           dt_frame, n, dx, dy, ox, oy, os, dok);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(x_new, ox, nd, hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipMemcpyAsync(y_new, oy, nd, hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipMemcpyAsync(speed, os, nd, hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipMemcpyAsync(ok, dok, (size_t)n, hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    return WT_OK;
+}

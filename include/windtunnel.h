@@ -156,6 +156,15 @@ int wt_field(wt_handle *h, int mode, double u0, double max_s, double cp_min, dou
 int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
                    double vort_scale, uint8_t *rgba_out);
 
+/* Replaces advect() (html:758-771) over sampleUV/sampleScalar (html:616-639) for n tracer
+ * particles at world positions (x,y): midpoint step through the velocity field normalised by u0
+ * (bilinear over fluid cells only).  dt_frame is the frame time in ms (html:903); the window is
+ * html:73's DX0,DX1,DY0,DY1.  ok[i]=0 where the reference returns null (outside the window or no
+ * fluid sample): x_new/y_new then repeat the input.  Whole-lattice handles only. */
+int wt_advect_tracers(wt_handle *h, int n, const double *x, const double *y, double dt_frame, double u0,
+                      double dx0, double dx1, double dy0, double dy1,
+                      double *x_new, double *y_new, double *speed, uint8_t *ok);
+
 int wt_sync(wt_handle *h);
 
 #ifdef __cplusplus

@@ -97,14 +97,25 @@ GEOMETRY_CASES = [
 
 RUN_CASES = [
     # name, nx, ny, shape, aoa, mode, u0, tau, steps, extras
-    dict(name="run_64x32_naca0012_a0_f32", nx=64, ny=32, shape="naca0012", aoa=0.0, mode="f32", u0=0.06, tau=None, steps=100, full=True, render=True),
+    dict(name="run_64x32_naca0012_a0_f32", nx=64, ny=32, shape="naca0012", aoa=0.0, mode="f32", u0=0.06, tau=None, steps=100, full=True, render=True, tracers=True),
     dict(name="run_64x32_naca0012_a0_f64", nx=64, ny=32, shape="naca0012", aoa=0.0, mode="f64", u0=0.06, tau=None, steps=100, full=True),
     dict(name="run_96x48_naca4412_a20_lowtau_f32", nx=96, ny=48, shape="naca4412", aoa=20.0, mode="f32", u0=0.10, tau=0.5004, steps=400, full=True),
     dict(name="run_96x48_sliders_f32", nx=96, ny=48, shape="naca2412", aoa=6.0, mode="f32", u0=0.06, tau=None, steps=120, full=True,
          aoa_schedule=[{"step": 40, "aoa": 14.5}, {"step": 80, "aoa": -3.0}], u0_schedule=[{"step": 60, "u0": 0.084}]),
-    dict(name="run_default_320x160_naca2412_a6_f32", nx=320, ny=160, shape="naca2412", aoa=6.0, mode="f32", u0=0.06, tau=None, steps=200, full=False),
+    dict(name="run_default_320x160_naca2412_a6_f32", nx=320, ny=160, shape="naca2412", aoa=6.0, mode="f32", u0=0.06, tau=None, steps=200, full=False, tracers=True),
     dict(name="run_cfg1_256x128_naca0012_a0_f32", nx=256, ny=128, shape="naca0012", aoa=0.0, mode="f32", u0=0.06, tau=None, steps=500, full=False),
 ]
+
+
+def tracer_points():
+    """Probe positions for advect(): a lattice of points over (and a little beyond) the window,
+    so that free-stream, near-body, in-body, edge-clamped and out-of-window cases all occur."""
+    pts = []
+    for a in range(-2, 40):
+        for b in range(-2, 22):
+            pts.append([-0.42 + 1.84 * (a + 0.37) / 37.0, -0.46 + 0.92 * (b + 0.41) / 19.0])
+    pts += [[-0.42, 0.0], [1.42, 0.0], [0.3, -0.46], [0.3, 0.46], [-0.4199, 0.4599], [1.4199, -0.4599], [0.25, 0.0], [0.0, 0.0]]
+    return pts
 
 
 def gen_geometry(only=None):
@@ -148,6 +159,8 @@ def gen_runs(only=None):
         for k in ("aoa_schedule", "u0_schedule"):
             if case.get(k):
                 run[k] = case[k]
+        if case.get("tracers"):
+            run["tracers"] = {"points": tracer_points(), "dt": 16.0}
         with tempfile.TemporaryDirectory() as tmp:
             res = run_harness({"nx": nx, "ny": ny, "opts": opts, "lattice": True, "init": {"u0": case["u0"]},
                                "geometry": {"shape": case["shape"], "aoa": case["aoa"], "mask_file": "mask.bin"},
@@ -175,6 +188,11 @@ def gen_runs(only=None):
                                fields_sha256=sha(fl))
                 if case.get("full"):
                     payload["fields"] = fl
+            if case.get("tracers"):
+                pts = np.asarray(tracer_points(), dtype=np.float64)
+                adv = np.asarray([[np.nan] * 3 if a is None else a for a in res["tracers"]], dtype=np.float64)
+                uv = np.asarray([[np.nan] * 2 if a is None else a for a in res["tracer_uv"]], dtype=np.float64)
+                payload.update(tracer_points=pts, tracer_advect=adv, tracer_uv=uv, tracer_dt=16.0)
             if case.get("render"):
                 payload["render_rgb"] = np.fromfile(os.path.join(tmp, "render.bin"), dtype=np.float32).reshape(3, ny, nx, 3)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **payload)

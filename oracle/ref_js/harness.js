@@ -59,6 +59,8 @@ function loadReference(htmlPath, nx, ny, opts) {
   const fields = between(txt, 'const Ufield=new Float32Array', 'function sampleScalar(', 'updateFieldsFromMacro (html:590-614)');
   const forces = between(txt, 'let CLsmooth=null', '// ================= colour maps', 'computeForces (html:641-700)');
   const cmaps = between(txt, 'function lerpScale(', '// ================= particle trail', 'colour maps (html:704-719)');
+  const sampling = between(txt, 'function sampleScalar(', 'let CLsmooth=null', 'sampleScalar/sampleUV (html:616-639)');
+  const particles = between(txt, 'let parts=[];', 'function w2cX(', 'particles (html:727-808)');
 
   const body = `
     ${domain}
@@ -73,7 +75,10 @@ function loadReference(htmlPath, nx, ny, opts) {
     ${fields}
     ${forces}
     ${cmaps}
+    ${sampling}
+    ${particles}
     return {
+      sampleUV, advect, spawn, initParts, getParts:()=>parts, STALL_SPEED2, STALL_DRAIN,
       DX0,DX1,DY0,DY1,CHORD_L,TAU,NU_L,STEPS_PER_FRAME,VORT_SCALE,NP,
       naca4,clarkY,SHAPES,rotate,panelise,rasterMask,buildGeometry,equilibriumInitData,
       STEP_FS_SRC,RENDER_FS_SRC,macro,
@@ -244,6 +249,11 @@ function main() {
       R.computeForces();
       const f2 = R.forceState();
       res.forces = { first: f1, second: f2 };
+      if (r.tracers) {
+        // advect() (html:758-771) on the fields updateFieldsFromMacro just filled
+        res.tracers = r.tracers.points.map((q) => { const a = R.advect({ x: q[0], y: q[1] }, r.tracers.dt); return a ? [a.nx, a.ny, a.speed] : null; });
+        res.tracer_uv = r.tracers.points.map((q) => R.sampleUV(q[0], q[1]));
+      }
       if (r.render_file) {
         const rg = res.ranges;
         const parts = [];

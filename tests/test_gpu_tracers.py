@@ -1,0 +1,95 @@
+"""GPU: tracer advection (wt_advect_tracers) against the reference's own advect()/sampleUV()
+(html:616-639, 758-771) run by Node on the golden macro fields; seeding statistics of the host
+particle system (html:730-753)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["run_64x32_naca0012_a0_f32", "run_default_320x160_naca2412_a6_f32"])
+def test_advect_matches_reference_js(pkg, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    with pkg.WindTunnel(shape=str(g["shape"]), nx=int(g["nx"]), ny=int(g["ny"]), aoa_deg=float(g["aoa"])) as wt:
+        wt.sim_step(int(g["steps"]))
+        pts, want = g["tracer_points"], g["tracer_advect"]
+        xn, yn, sp, ok = wt.engine.advect_tracers(pts[:, 0], pts[:, 1], float(g["tracer_dt"]), wt.u0, (-0.42, 1.42, -0.46, 0.46))
+        null = np.isnan(want[:, 0])
+        assert np.array_equal(~ok, null) and null.sum() > 50 and (~null).sum() > 500
+        np.testing.assert_allclose(np.stack([xn, yn, sp], 1)[ok], want[~null], rtol=1e-12, atol=1e-14)
+        assert np.array_equal(xn[~ok], pts[~ok, 0])
+
+
+def test_particle_system_statistics(pkg):
+    """Seeding mirrors initParts/spawn: lanes span the window, 35 % centre band, ages uniform; a few
+    hundred frames keep every particle inside the window and the population constant."""
+    with pkg.WindTunnel(nx=320, ny=160) as wt:
+        wt.sim_step(200)
+        wt.update_fields_from_macro()
+        tr = pkg.Tracers(wt, n=2600, seed=7)
+        assert tr.x.size == 2600 and tr.x.min() >= -0.42 and tr.x.max() <= -0.42 + 1.84 * 0.95
+        centre = np.abs(tr.lane) < 0.92 / 6
+        assert 0.50 < centre.mean() < 0.62            # 35 % forced + a third of the uniform 65 %
+        assert 0 < tr.life.min() and tr.life.max() <= 520 and 150 < tr.life.mean() < 220
+        moved = 0
+        for _ in range(120):
+            seg, t = tr.step(16.0)
+            moved += len(seg)
+            assert seg.shape[1] == 4 and ((t >= 0) & (t <= 1)).all()
+            assert tr.x.size == 2600 and np.isfinite(tr.x).all() and np.isfinite(tr.y).all()
+            assert tr.x.min() >= -0.42 - 1e-9 and tr.x.max() <= 1.42 + 0.06 and np.abs(tr.y).max() <= 0.46 + 0.06
+        assert moved > 0.9 * 120 * 2600
+        # free-stream particles drift downstream at ~U0-normalised speed 1: 0.00105*16 per frame
+        tr.resize(800); assert tr.x.size == 800
+        tr.resize(3000); assert tr.x.size == 3000
+
+
+class _FakeStreamlit:
+    """Just enough of the streamlit API for build_lbm_component (streamlit is not installed here)."""
+
+    def __init__(self):
+        self.session_state = {}
+        self.calls = []
+
+    def slider(self, label, lo, hi, value, step):
+        self.calls.append(("slider", label))
+        return {"Angle of attack": 8.0}.get(label, value)
+
+    def selectbox(self, label, options):
+        self.calls.append(("selectbox", label))
+        return options[1]
+
+    def image(self, img, caption=None, use_column_width=None):
+        self.calls.append(("image", img.shape, img.dtype))
+
+    def columns(self, n):
+        outer = self
+
+        class Col:
+            def metric(self, label, value):
+                outer.calls.append(("metric", label, value))
+        return [Col() for _ in range(n)]
+
+    def error(self, msg):
+        self.calls.append(("error", msg))
+
+
+def test_streamlit_page_wiring(pkg):
+    from airfoil_cfd_tool_amd.streamlit_page import build_lbm_component
+    st = _FakeStreamlit()
+    coords = pkg.geometry.SHAPES["naca4412"]()
+    wt = build_lbm_component(coords, "NACA 4412", nx=256, ny=128, frames_per_rerun=6, st=st)
+    try:
+        assert wt is not None and wt.aoa_deg == 8.0 and wt.field == "cp" and wt.steps == 24
+        assert ("image", (128, 256, 4), np.dtype(np.uint8)) in st.calls
+        metrics = {c[1]: c[2] for c in st.calls if c[0] == "metric"}
+        assert set(metrics) == {"CL (approx)", "CD (approx)", "Reynolds", "Separation"} and metrics["Reynolds"] == "313"
+        again = build_lbm_component(coords, "NACA 4412", nx=256, ny=128, frames_per_rerun=3, st=st)
+        assert again is wt and wt.steps == 36                      # same session -> same tunnel keeps running
+    finally:
+        wt.close()
