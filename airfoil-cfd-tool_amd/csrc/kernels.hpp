@@ -31,9 +31,10 @@ struct Geom {
 enum : uint8_t { TILE_GENERAL = 0, TILE_FAST = 1, TILE_SOLID = 2, TILE_INLET = 3, TILE_OUTLET = 4 };
 
 // --------------------------------------------------------------------------------------
-// k_step_general: one thread per lattice site, every branch of STEP_FS main()
-// (html:283-360) taken per lane.  Correct for any site; used for tiles that touch the
-// body or when vector paths do not apply.
+// site_general: one lattice site, every branch of STEP_FS main() (html:283-360) taken per
+// lane.  Correct for any site; used by the tiles that touch the body surface and by ragged
+// tiles.  (A 4-sites-per-lane vector form of this path was measured SLOWER on the 4096^2
+// body case, 213 vs 207 us per step: its 111 VGPRs cost the whole kernel two waves per SIMD.)
 // --------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void site_general(const T *__restrict__ s, T *__restrict__ d, T *__restrict__ macro,
@@ -74,20 +75,6 @@ __device__ __forceinline__ void site_general(const T *__restrict__ s, T *__restr
         const long mp = (long)g.nxl * g.pitch;
         macro[c] = rho; macro[mp + c] = ux; macro[2 * mp + c] = uy;
     }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_step_general(const T *__restrict__ fs, T *__restrict__ fd,
-                                                      T *__restrict__ macro, const uint8_t *__restrict__ mask,
-                                                      Geom g, int i_begin, int i_end, T tau, T U0, int emit)
-{
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= g.ny) return;
-    const T *s = fs + g.pitch;            // skip the pad column
-    T *d = fd + g.pitch;
-    const uint8_t *m = mask + g.pitch;
-    for (int i = i_begin + blockIdx.y; i < i_end; i += gridDim.y)
-        site_general<T>(s, d, macro, m, g, i, j, tau, U0, emit != 0);
 }
 
 // --------------------------------------------------------------------------------------
