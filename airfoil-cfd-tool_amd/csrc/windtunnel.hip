@@ -368,18 +368,20 @@ static int exchange_rccl(wt_handle *h)
 {
     const size_t count = (size_t)h->halo * h->g.pitch;   // elements per population per side
     const ncclDataType_t dt = h->dtype == WT_F32 ? ncclFloat32 : ncclFloat64;
-    NCCL_TRY(ncclGroupStart());
-    for (int k = 0; k < 9; k++) {
+    ncclResult_t rc = ncclGroupStart();
+    for (int k = 0; k < 9 && rc == ncclSuccess; k++) {
         if (h->gl) {   // left neighbour: send my first `halo` owned columns, receive my left ghosts
-            NCCL_TRY(ncclSend(col_ptr(h, h->cur, k, h->gl), count, dt, h->rank - 1, h->comm, h->s_comm));
-            NCCL_TRY(ncclRecv(col_ptr(h, h->cur, k, 0), count, dt, h->rank - 1, h->comm, h->s_comm));
+            rc = ncclSend(col_ptr(h, h->cur, k, h->gl), count, dt, h->rank - 1, h->comm, h->s_comm);
+            if (rc == ncclSuccess) rc = ncclRecv(col_ptr(h, h->cur, k, 0), count, dt, h->rank - 1, h->comm, h->s_comm);
         }
-        if (h->gr) {   // right neighbour: send my last `halo` owned columns, receive my right ghosts
-            NCCL_TRY(ncclSend(col_ptr(h, h->cur, k, h->gl + h->width - h->halo), count, dt, h->rank + 1, h->comm, h->s_comm));
-            NCCL_TRY(ncclRecv(col_ptr(h, h->cur, k, h->gl + h->width), count, dt, h->rank + 1, h->comm, h->s_comm));
+        if (h->gr && rc == ncclSuccess) {   // right neighbour: send my last `halo` owned columns, receive my right ghosts
+            rc = ncclSend(col_ptr(h, h->cur, k, h->gl + h->width - h->halo), count, dt, h->rank + 1, h->comm, h->s_comm);
+            if (rc == ncclSuccess) rc = ncclRecv(col_ptr(h, h->cur, k, h->gl + h->width), count, dt, h->rank + 1, h->comm, h->s_comm);
         }
     }
-    NCCL_TRY(ncclGroupEnd());
+    const ncclResult_t rc_end = ncclGroupEnd();            // always close the group, even after a failure
+    if (rc == ncclSuccess) rc = rc_end;
+    if (rc != ncclSuccess) return fail(WT_ERR_RCCL, "ghost-column exchange failed: %s", ncclGetErrorString(rc));
     return WT_OK;
 }
 

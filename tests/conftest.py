@@ -16,19 +16,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def _gpu_available() -> bool:
-    try:
-        import torch
-        return bool(torch.cuda.is_available())
-    except Exception:
-        return False
-
-
-def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must fail loudly, not skip: the product has no CPU path.
-    pass
-
-
 @pytest.fixture(scope="session")
 def oracle_np():
     import lbm_numpy
