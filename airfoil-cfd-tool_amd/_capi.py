@@ -22,6 +22,7 @@ WT_COMM_ID_BYTES = 128
 
 EXPORTS = (
     "wt_create", "wt_create_slab", "wt_destroy", "wt_get_info", "wt_last_error", "wt_version",
+    "wt_set_option", "wt_get_option",
     "wt_comm_unique_id", "wt_comm_init_rank", "wt_link_local", "wt_step_group",
     "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_read_f", "wt_write_f",
     "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_field", "wt_render_rgba", "wt_advect_tracers", "wt_sync",
@@ -70,6 +71,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "wt_get_info": ([H, POINTER(WtInfo)], c_int),
         "wt_last_error": ([], c_char_p),
         "wt_version": ([], c_char_p),
+        "wt_set_option": ([H, c_char_p, c_double], c_int),
+        "wt_get_option": ([H, c_char_p, POINTER(c_double)], c_int),
         "wt_comm_unique_id": ([c_void_p], c_int),
         "wt_comm_init_rank": ([H, c_void_p], c_int),
         "wt_link_local": ([POINTER(H), c_int], c_int),
@@ -149,6 +152,14 @@ class Engine:
         info = WtInfo()
         _check(self._lib.wt_get_info(self._h, byref(info)))
         return info
+
+    def set_option(self, name: str, value: float) -> None:
+        _check(self._lib.wt_set_option(self._h, name.encode(), float(value)))
+
+    def get_option(self, name: str) -> float:
+        v = c_double()
+        _check(self._lib.wt_get_option(self._h, name.encode(), byref(v)))
+        return v.value
 
     # -- transports --
     @staticmethod

@@ -18,6 +18,7 @@
 #include "../../include/windtunnel.h"
 #include "kernels.hpp"
 #include "step_fast.hpp"
+#include "step_fused.hpp"
 
 using namespace wt;
 
@@ -88,6 +89,15 @@ struct wt_handle {
     int transport = TR_NONE;
     ncclComm_t comm = nullptr;
     wt_handle *peer_l = nullptr, *peer_r = nullptr;   // TR_LOCAL
+    // two-steps-per-launch mode (step_fused.hpp); whole-lattice fp32 handles only
+    bool fuse = false;
+    int fuse_chunk = 24;
+    bool fuse_ready = false;
+    void *f_tmp = nullptr;               // third lattice for the non-fusable zone
+    FuseUnit *d_units = nullptr;
+    int *d_t1 = nullptr, *d_t2 = nullptr;
+    int n_units = 0, n_t1 = 0, n_t2 = 0;
+    std::vector<uint8_t> host_mask;      // copy of the last mask (plan rebuilds when an option changes)
 };
 
 static const int kReduceBlocks = 1024;
@@ -193,6 +203,12 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     CREATE_TRY(hipMemsetAsync(h->tiles, 0, tile_bytes, h->s_compute));
     CREATE_TRY(hipStreamSynchronize(h->s_compute));
 #undef CREATE_TRY
+    {
+        const char *e = getenv("WT_FUSE2");
+        h->fuse = e && atoi(e) != 0;
+        const char *c = getenv("WT_FUSE_CHUNK");
+        if (c && atoi(c) > 0) h->fuse_chunk = atoi(c);
+    }
     *out = h;
     return WT_OK;
 }
@@ -222,6 +238,10 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->mask) (void)hipFree(h->mask);
     if (h->tiles) (void)hipFree(h->tiles);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->f_tmp) (void)hipFree(h->f_tmp);
+    if (h->d_units) (void)hipFree(h->d_units);
+    if (h->d_t1) (void)hipFree(h->d_t1);
+    if (h->d_t2) (void)hipFree(h->d_t2);
     if (h->partials) (void)hipFree(h->partials);
     if (h->partials_host) (void)hipHostFree(h->partials_host);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -254,6 +274,77 @@ extern "C" int wt_sync(wt_handle *h)
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_comm));
     return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// two-steps-per-launch plan
+// ------------------------------------------------------------------------------------------
+static bool fuse_eligible(const wt_handle *h) { return h->nranks == 1 && h->dtype == WT_F32 && h->g.ny % 4 == 0; }
+
+template <typename U>
+static int upload_vec(U **dptr, const std::vector<U> &v, wt_handle *h)
+{
+    if (*dptr) { HIP_TRY(hipFree(*dptr)); *dptr = nullptr; }
+    if (v.empty()) return WT_OK;
+    HIP_TRY(hipMalloc((void **)dptr, v.size() * sizeof(U)));
+    HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice));
+    (void)h;
+    return WT_OK;
+}
+
+static int rebuild_fuse_plan(wt_handle *h)
+{
+    h->fuse_ready = false;
+    if (!h->fuse || !fuse_eligible(h) || h->host_mask.empty()) return WT_OK;
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    const FusePlan p = build_fuse_plan(h->host_mask.data(), h->g.nx_g, h->g.ny, h->tiles_per_col, h->fuse_chunk);
+    if (!p.usable) return WT_OK;
+    WT_TRY(upload_vec(&h->d_units, p.units, h));
+    WT_TRY(upload_vec(&h->d_t1, p.t1, h));
+    WT_TRY(upload_vec(&h->d_t2, p.t2, h));
+    h->n_units = (int)p.units.size(); h->n_t1 = (int)p.t1.size(); h->n_t2 = (int)p.t2.size();
+    if (!h->f_tmp) {
+        const size_t lat_bytes = (size_t)9 * h->g.plane * h->esz;
+        HIP_TRY(hipMalloc(&h->f_tmp, lat_bytes));
+        // on the compute stream (a blocking-API hipMemset on the null stream is not ordered against
+        // this handle's non-blocking streams and could land after the first pass has written C)
+        HIP_TRY(hipMemsetAsync(h->f_tmp, 0, lat_bytes, h->s_compute));
+        HIP_TRY(hipStreamSynchronize(h->s_compute));
+        h->device_bytes += (long long)lat_bytes;
+    }
+    h->fuse_ready = true;
+    return WT_OK;
+}
+
+extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
+{
+    WT_TRY(check_handle(h));
+    if (!name) return fail(WT_ERR_ARG, "option name is null");
+    HIP_TRY(hipSetDevice(h->device));
+    if (strcmp(name, "fuse_steps") == 0) {
+        if (value != 0.0 && !fuse_eligible(h))
+            return fail(WT_ERR_STATE, "fuse_steps needs a whole-lattice fp32 handle with NY %% 4 == 0");
+        h->fuse = value != 0.0;
+        return rebuild_fuse_plan(h);
+    }
+    if (strcmp(name, "fuse_chunk") == 0) {
+        if (!(value >= 1.0 && value <= 4096.0)) return fail(WT_ERR_ARG, "fuse_chunk out of range");
+        h->fuse_chunk = (int)value;
+        return rebuild_fuse_plan(h);
+    }
+    return fail(WT_ERR_ARG, "unknown option '%s'", name);
+}
+
+extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value)
+{
+    WT_TRY(check_handle(h));
+    if (!name || !value) return fail(WT_ERR_ARG, "null argument");
+    if (strcmp(name, "fuse_steps") == 0) { *value = h->fuse ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "fuse_active") == 0) { *value = h->fuse_ready ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_chunk; return WT_OK; }
+    if (strcmp(name, "fuse_units") == 0) { *value = h->n_units; return WT_OK; }
+    if (strcmp(name, "fuse_tiles_single") == 0) { *value = h->n_t2; return WT_OK; }
+    return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -300,6 +391,10 @@ extern "C" int wt_set_mask(wt_handle *h, const uint8_t *mask)
     WT_TRY(classify_tiles(h->mask, h->tiles, g, h->tiles_per_col, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     h->mask_set = true;
+    if (fuse_eligible(h)) {
+        h->host_mask.assign(mask, mask + (size_t)g.nx_g * g.ny);
+        WT_TRY(rebuild_fuse_plan(h));
+    }
     return WT_OK;
 }
 
@@ -463,13 +558,69 @@ static int step_once(wt_handle *h, double tau, double u0, bool emit)
     return step_compute(h, tau, u0, emit, refresh);
 }
 
+// Two steps in one pass over the lattice (step_fused.hpp).  A = f[cur] (time t), B = f[1-cur]
+// (receives time t+2), C = f_tmp (time t+1 on the tiles of the non-fusable zone only).
+static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
+{
+    const Geom &g = h->g;
+    const float *A = fptr<float>(h, h->cur);
+    float *B = fptr<float>(h, 1 - h->cur);
+    float *C = reinterpret_cast<float *>(h->f_tmp);
+    float *macro = reinterpret_cast<float *>(h->macro);
+    const int rev = (int)((h->steps_done >> 1) & 1);
+    const float t = (float)tau, U = (float)u0;
+    // The two single-step passes over the body zone (small launches) run on the second stream,
+    // concurrently with the fused kernel: all three only read A; B is written on disjoint (or
+    // identically valued) sites; C belongs to the passes alone.
+    hipStream_t st = h->s_compute, sz = h->s_comm;
+    const bool zone = h->n_t1 > 0 || h->n_t2 > 0;
+    if (zone) {
+        HIP_TRY(hipEventRecord(h->ev_state, st));
+        HIP_TRY(hipStreamWaitEvent(sz, h->ev_state, 0));
+        if (h->n_t1)
+            hipLaunchKernelGGL((k_step_list<float, false, WT_LOADMODE>), dim3((h->n_t1 + 3) / 4), dim3(256), 0, sz, A, C, macro, h->mask,
+                               h->tiles, h->tiles_per_col, g, (const int *)h->d_t1, h->n_t1, t, U, rev);
+        if (h->n_t2) {
+            if (emit)
+                hipLaunchKernelGGL((k_step_list<float, true, WT_LOADMODE>), dim3((h->n_t2 + 3) / 4), dim3(256), 0, sz, (const float *)C, B,
+                                   macro, h->mask, h->tiles, h->tiles_per_col, g, (const int *)h->d_t2, h->n_t2, t, U, rev);
+            else
+                hipLaunchKernelGGL((k_step_list<float, false, WT_LOADMODE>), dim3((h->n_t2 + 3) / 4), dim3(256), 0, sz, (const float *)C, B,
+                                   macro, h->mask, h->tiles, h->tiles_per_col, g, (const int *)h->d_t2, h->n_t2, t, U, rev);
+        }
+        HIP_TRY(hipEventRecord(h->ev_halo, sz));
+    }
+    if (emit)
+        hipLaunchKernelGGL((k_step2<true>), dim3((h->n_units + 3) / 4), dim3(256), 0, st, A, B, macro, (const FuseUnit *)h->d_units,
+                           h->n_units, g, t, U, rev);
+    else
+        hipLaunchKernelGGL((k_step2<false>), dim3((h->n_units + 3) / 4), dim3(256), 0, st, A, B, macro, (const FuseUnit *)h->d_units,
+                           h->n_units, g, t, U, rev);
+    if (zone) HIP_TRY(hipStreamWaitEvent(st, h->ev_halo, 0));
+    HIP_TRY(hipGetLastError());
+    h->cur = 1 - h->cur;
+    h->steps_done += 2;
+    return WT_OK;
+}
+
+static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
+{
+    int s = 0;
+    if (h->fuse_ready && h->nranks == 1 && nsteps >= 2) {
+        if (nsteps & 1) { WT_TRY(step_once(h, tau, u0, false)); s = 1; }
+        for (; s < nsteps; s += 2) WT_TRY(step_pair_fused(h, tau, u0, s + 2 == nsteps));
+        return WT_OK;
+    }
+    for (; s < nsteps; s++) WT_TRY(step_once(h, tau, u0, s == nsteps - 1));
+    return WT_OK;
+}
+
 extern "C" int wt_step(wt_handle *h, int nsteps, double tau, double u0)
 {
     WT_TRY(check_steppable(h, nsteps, tau, u0));
     if (h->transport == TR_LOCAL) return fail(WT_ERR_STATE, "locally linked slabs are stepped with wt_step_group");
     HIP_TRY(hipSetDevice(h->device));
-    for (int s = 0; s < nsteps; s++) WT_TRY(step_once(h, tau, u0, s == nsteps - 1));
-    return WT_OK;
+    return run_steps(h, nsteps, tau, u0);
 }
 
 extern "C" int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, float *elapsed_ms)
@@ -479,7 +630,7 @@ extern "C" int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, fl
     if (h->transport == TR_LOCAL) return fail(WT_ERR_STATE, "locally linked slabs are stepped with wt_step_group");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipEventRecord(h->ev_a, h->s_compute));
-    for (int s = 0; s < nsteps; s++) WT_TRY(step_once(h, tau, u0, s == nsteps - 1));
+    WT_TRY(run_steps(h, nsteps, tau, u0));
     HIP_TRY(hipEventRecord(h->ev_b, h->s_compute));
     HIP_TRY(hipEventSynchronize(h->ev_b));
     HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev_a, h->ev_b));

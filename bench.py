@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--tau", type=float, default=0.58)
     ap.add_argument("--halo", type=int, default=16, help="ghost columns per interior slab side (exchange every `halo` steps)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the NumPy CPU baseline (0 = skip)")
+    ap.add_argument("--fuse", type=int, default=0, choices=[0, 1],
+                    help="1: two steps per pass over the lattice (csrc/step_fused.hpp; single GPU, fp32; bit-identical)")
+    ap.add_argument("--fuse-chunk", type=int, default=24)
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -121,6 +124,9 @@ def main():
         eng.comm_init_rank(ids[0])
     else:
         eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank)
+        if args.fuse:
+            eng.set_option("fuse_chunk", args.fuse_chunk)
+            eng.set_option("fuse_steps", 1)
     eng.set_mask(mask)
     eng.init_equilibrium(args.u0)
 
@@ -151,9 +157,12 @@ def main():
     sites = nx_total * ny
     mlups = sites * args.steps / wall / 1e6
     bpl = BYTES_PER_LUP[args.dtype]
+    fused = bool(not distributed and args.fuse and eng.get_option("fuse_active"))
     launch_ms = dev_ms / args.steps                      # one step = one launch of k_step over the slab
+    if fused:
+        launch_ms *= 2.0                                 # one pass (k_step2 + the two list passes) = TWO steps
     sites_per_launch = eng.width * ny if not distributed else (nx_total // world) * ny
-    achieved = bpl * sites_per_launch / (launch_ms * 1e-3) / 1e9
+    achieved = bpl * sites_per_launch * (2 if fused else 1) / (launch_ms * 1e-3) / 1e9
     workload = (f"{args.shape.upper()} {nx_total}x{ny} {args.dtype} D2Q9, AoA={args.aoa:g} deg, U0={args.u0:g}, "
                 f"tau={args.tau:g} (BASELINE configs[2]; S1223 coordinates unavailable offline -> NACA 6409)")
     out = {
@@ -170,17 +179,17 @@ def main():
         "dtype": "f32" if args.dtype == "float32" else "f64",
         "data": "synthetic",
         "config": {"workload": workload, "nx": nx_total, "ny": ny, "slabs": world,
-                   "halo": args.halo if distributed else 0,
+                   "halo": args.halo if distributed else 0, "fuse_steps": int(fused),
                    "solid_sites": int((mask != 0).sum())},
         "roofline": {
             "bound": "hbm",
-            "kernel": "wt::k_step",
+            "kernel": "wt::k_step2 (+ k_step_list x2 on the body zone), two steps per pass" if fused else "wt::k_step",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": measured_traffic(f"{nx_total}x{ny}_{args.dtype}") if not distributed else None,
-            "algorithmic_bytes_per_launch": bpl * sites_per_launch,
+            "algorithmic_bytes_per_launch": bpl * sites_per_launch * (2 if fused else 1),
             "launch_ms": launch_ms,
         },
     }

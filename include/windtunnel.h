@@ -82,6 +82,14 @@ int wt_get_info(const wt_handle *h, wt_info *info);
 const char *wt_last_error(void);
 const char *wt_version(void);
 
+/* Tuning knobs (no counterpart in the reference).  "fuse_steps" (0/1): advance TWO steps per pass
+ * over the lattice where the flow is plain (temporal fusion in registers, csrc/step_fused.hpp);
+ * results are bit-identical either way.  Whole-lattice fp32 handles with NY % 4 == 0; default off
+ * (environment WT_FUSE2=1 turns it on at wt_create).  "fuse_chunk": columns per marching chunk.
+ * wt_get_option also reports "fuse_active", "fuse_units", "fuse_tiles_single". */
+int wt_set_option(wt_handle *h, const char *name, double value);
+int wt_get_option(const wt_handle *h, const char *name, double *value);
+
 /* ---- ghost-column transport for slab handles -------------------------------- */
 
 /* RCCL over xGMI, one process per GPU: rank 0 calls wt_comm_unique_id, the host

@@ -1,0 +1,109 @@
+"""GPU: the opt-in two-steps-per-launch mode (csrc/step_fused.hpp) must be bit-identical to the
+ordinary single-step path and to the oracle: fused units (register-resident step 1 -> step 2),
+the single-step passes through the third lattice for the body zone, odd/even step counts, macro
+emission, mask changes, chunk sizes."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None):
+    ny, nx = mask.shape
+    with pkg.Engine(nx, ny) as e:
+        if fuse:
+            if chunk is not None:
+                e.set_option("fuse_chunk", chunk)
+            e.set_option("fuse_steps", 1)
+        e.set_mask(mask)
+        e.init_equilibrium(u0)
+        if fuse:
+            assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_units") > 0
+        for n in chunks:
+            e.step(n, tau, u0)
+        return e.read_f(), e.read_macro(), e.info().steps_done
+
+
+def _body(pkg, nx, ny, shape="naca2412", aoa=7.0):
+    return pkg.geometry.build_geometry(nx, ny, aoa, None, shape).mask
+
+
+@pytest.mark.parametrize("nx,ny,chunks,chunk", [
+    (512, 256, [2], None),
+    (512, 256, [1, 2, 3, 4, 5, 6, 17], None),
+    (512, 256, [40], 1),
+    (512, 256, [40], 7),
+    (512, 256, [41], 100),
+    (1024, 512, [64, 3], None),
+    (384, 768, [30], 16),            # three windows per column
+    (200, 1024, [21], 5),            # narrow, tall: five windows, body crosses window seams
+    (2048, 1024, [12], None),
+])
+def test_fused_equals_single_step(pkg, nx, ny, chunks, chunk):
+    mask = _body(pkg, nx, ny)
+    f0, m0, n0 = _run(pkg, mask, chunks, 0.58, 0.06, False)
+    f1, m1, n1 = _run(pkg, mask, chunks, 0.58, 0.06, True, chunk)
+    assert n0 == n1 == sum(chunks)
+    assert bits_equal(f0, f1)
+    assert all(bits_equal(a, b) for a, b in zip(m0, m1))
+
+
+def test_fused_vs_oracle_and_edge_masks(pkg, oracle_c):
+    nx, ny = 512, 512
+    empty = np.zeros((ny, nx), np.uint8)
+    wall = np.zeros((ny, nx), np.uint8); wall[:, 200:204] = 1
+    specks = np.zeros((ny, nx), np.uint8); specks[::37, ::53] = 1; specks[255:257, 100:110] = 1; specks[251:254, 300] = 1
+    edges = np.zeros((ny, nx), np.uint8); edges[0, 10:20] = 1; edges[ny - 1, 30:40] = 1; edges[50:60, 0] = 1; edges[70:90, nx - 1] = 1; edges[100:140, 2] = 1
+    for mask in (empty, wall, specks, edges, _body(pkg, nx, ny, "naca4412", 15.0)):
+        f, m, _ = _run(pkg, mask, [8, 9], 0.58, 0.06, True, 12)
+        fr, mr = oracle_c.run(mask, 17, 0.58, 0.06, np.float32)
+        assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr))
+
+
+def test_fused_low_tau_clamp_and_mask_change(pkg, oracle_c):
+    nx, ny = 512, 256
+    m1, m2 = _body(pkg, nx, ny, "naca4412", 20.0), _body(pkg, nx, ny, "naca4412", 5.0)
+    with pkg.Engine(nx, ny) as e:
+        e.set_option("fuse_steps", 1)
+        e.set_mask(m1); e.init_equilibrium(0.10); e.step(300, 0.5004, 0.10)
+        e.set_mask(m2); e.step(100, 0.5004, 0.09)
+        f, m = e.read_f(), e.read_macro()
+    fr, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float32)
+    fr, mr = oracle_c.run(m2, 100, 0.5004, 0.09, np.float32, f=fr)
+    assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr))
+
+
+def test_fused_toggle_midrun_and_4096(pkg):
+    nx = ny = 4096
+    mask = _body(pkg, nx, ny, "naca6409", 10.0)
+    with pkg.Engine(nx, ny) as a, pkg.Engine(nx, ny) as b:
+        for e in (a, b):
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        a.step(9, 0.58, 0.06)
+        b.step(3, 0.58, 0.06)
+        b.set_option("fuse_steps", 1)            # option set after the mask: the plan is rebuilt from the kept copy
+        assert b.get_option("fuse_active") == 1.0
+        b.step(4, 0.58, 0.06)
+        b.set_option("fuse_steps", 0)
+        b.step(2, 0.58, 0.06)
+        assert bits_equal(a.read_f(), b.read_f())
+        assert all(bits_equal(x, y) for x, y in zip(a.read_macro(), b.read_macro()))
+        single = b.get_option("fuse_tiles_single")
+        assert 0 < single < 0.35 * nx * (ny // 256)
+
+
+def test_fused_not_available(pkg):
+    with pkg.Engine(256, 128, dtype="float64") as e:
+        with pytest.raises(pkg.WTError):
+            e.set_option("fuse_steps", 1)
+    with pkg.Engine(256, 130) as e:
+        with pytest.raises(pkg.WTError):
+            e.set_option("fuse_steps", 1)
+        with pytest.raises(pkg.WTError):
+            e.set_option("no_such_option", 1)
+    with pkg.Engine(64, 64) as e:               # eligible but tiny: a plan with few units still works
+        e.set_option("fuse_steps", 1)
+        e.set_mask(np.zeros((64, 64), np.uint8)); e.init_equilibrium(0.06); e.step(6, 0.58, 0.06)
+        assert e.info().steps_done == 6

@@ -1,0 +1,310 @@
+// kfuse.hip — prototype: TWO lattice steps per launch, register-resident, wave-private windows.
+// Each wave owns a window of 256 rows (j) and marches along a chunk of L columns (i): it computes
+// step 1 for column c+1 from HBM (9 sixteen-byte loads), keeps the post-collision populations of the
+// last three columns in registers, and computes step 2 for column c from them (the +-1 shifts along j
+// are lane shuffles; the two window-edge sites are not produced — windows overlap by 4 rows).
+// Developer experiment: measures the speed and checks bit-equality with two production steps.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+#include "../airfoil-cfd-tool_amd/csrc/kernels.hpp"
+#include "../airfoil-cfd-tool_amd/csrc/step_fast.hpp"
+
+using namespace wt;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef Vec<float> V4;
+
+// step 1 of one column `col` for this lane's 4 rows starting at j0 (FAST semantics + top/bottom far field)
+__device__ __forceinline__ void step1_column(const float *__restrict__ s, const Geom &g, long P, int col, int j0, float tau, const float (&feq0)[9], V4 (&G)[9])
+{
+    const long c = (long)col * g.pitch + j0;
+    V4 fin[9];
+    fin[0] = vload<float, true>(s + 0 * P + c);
+    fin[1] = vload<float, true>(s + 1 * P + c - g.pitch);
+    fin[3] = vload<float, true>(s + 3 * P + c + g.pitch);
+    fin[2] = vload<float, true, true>(s + 2 * P + c - 1);
+    fin[5] = vload<float, true, true>(s + 5 * P + c - g.pitch - 1);
+    fin[6] = vload<float, true, true>(s + 6 * P + c + g.pitch - 1);
+    fin[4] = vload<float, true, true>(s + 4 * P + c + 1);
+    fin[7] = vload<float, true, true>(s + 7 * P + c + g.pitch + 1);
+    fin[8] = vload<float, true, true>(s + 8 * P + c - g.pitch + 1);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        float a[9], o[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+        collide<float>(a, tau, o, rho, ux, uy);
+        const int j = j0 + v;
+        const bool far = (j == 0) || (j == g.ny - 1);
+#pragma unroll
+        for (int k = 0; k < 9; k++) G[k].v[v] = far ? feq0[k] : o[k];
+    }
+}
+
+__device__ __forceinline__ V4 from_below(const V4 &r)   // value at j-1 (lane 0 / v 0 is garbage)
+{
+    V4 o;
+    o.v[0] = lane_up(r.v[3]);
+    o.v[1] = r.v[0]; o.v[2] = r.v[1]; o.v[3] = r.v[2];
+    return o;
+}
+__device__ __forceinline__ V4 from_above(const V4 &r)   // value at j+1 (lane 63 / v 3 is garbage)
+{
+    V4 o;
+    o.v[0] = r.v[1]; o.v[1] = r.v[2]; o.v[2] = r.v[3];
+    o.v[3] = lane_down(r.v[0]);
+    return o;
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_step2(const float *__restrict__ fs, float *__restrict__ fd, Geom g, int ca, int cb, int nwin, float tau, float U0, int rev)
+{
+    const int lane = threadIdx.x & 63;
+    const int nchunk = (cb - ca + L - 1) / L;
+    long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nunits = (long)nchunk * nwin;
+    if (unit >= nunits) return;
+    if (rev) unit = nunits - 1 - unit;
+    const int q = (int)(unit / nwin), w = (int)(unit % nwin);
+    const int ia = ca + q * L, ib = min(ia + L, cb);
+    const int j0 = w * 252 + lane * 4;
+    const float *s = fs + g.pitch;
+    float *d = fd + g.pitch;
+    const long P = g.plane;
+    float feq0[9];
+    feq_all<float>(1.0f, U0, 0.0f, feq0);
+
+    V4 Gm[9], Gc[9], Gp[9];          // step-1 results of columns c-1, c, c+1
+    step1_column(s, g, P, ia - 1, j0, tau, feq0, Gm);
+    step1_column(s, g, P, ia, j0, tau, feq0, Gc);
+    const bool first_win = (w == 0);
+#pragma unroll 1
+    for (int c = ia; c < ib; c++) {
+        step1_column(s, g, P, c + 1, j0, tau, feq0, Gp);
+        V4 fin[9];
+        fin[0] = Gc[0]; fin[1] = Gm[1]; fin[3] = Gp[3];
+        fin[2] = from_below(Gc[2]); fin[5] = from_below(Gm[5]); fin[6] = from_below(Gp[6]);
+        fin[4] = from_above(Gc[4]); fin[8] = from_above(Gm[8]); fin[7] = from_above(Gp[7]);
+        V4 out[9];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            float a[9], o[9], rho, ux, uy;
+#pragma unroll
+            for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+            collide<float>(a, tau, o, rho, ux, uy);
+            const int j = j0 + v;
+            const bool far = (j == 0) || (j == g.ny - 1);
+#pragma unroll
+            for (int k = 0; k < 9; k++) out[k].v[v] = far ? feq0[k] : o[k];
+        }
+        const long cc = (long)c * g.pitch + j0;
+        if (j0 + 3 < g.ny) {
+            if (lane == 0 && !first_win) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(d + k * P + cc + 2) = make_float2(out[k].v[2], out[k].v[3]);
+            } else if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(d + k * P + cc) = make_float2(out[k].v[0], out[k].v[1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; k++) vstore<float>(d + k * P + cc, out[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) { Gm[k] = Gc[k]; Gc[k] = Gp[k]; }
+    }
+}
+
+// ---- variant with software prefetch: the 9 input vectors of column c+2 are requested before the
+// ---- arithmetic of column c+1 / c starts, so HBM latency overlaps a whole iteration of VALU work.
+__device__ __forceinline__ void load_inputs(const float *__restrict__ s, const Geom &g, long P, int col, int j0, V4 (&fin)[9])
+{
+    const long c = (long)col * g.pitch + j0;
+    fin[0] = vload<float, true>(s + 0 * P + c);
+    fin[1] = vload<float, true>(s + 1 * P + c - g.pitch);
+    fin[3] = vload<float, true>(s + 3 * P + c + g.pitch);
+    fin[2] = vload<float, true, true>(s + 2 * P + c - 1);
+    fin[5] = vload<float, true, true>(s + 5 * P + c - g.pitch - 1);
+    fin[6] = vload<float, true, true>(s + 6 * P + c + g.pitch - 1);
+    fin[4] = vload<float, true, true>(s + 4 * P + c + 1);
+    fin[7] = vload<float, true, true>(s + 7 * P + c + g.pitch + 1);
+    fin[8] = vload<float, true, true>(s + 8 * P + c - g.pitch + 1);
+}
+__device__ __forceinline__ void collide_column(const V4 (&fin)[9], const Geom &g, int j0, float tau, const float (&feq0)[9], V4 (&G)[9])
+{
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        float a[9], o[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+        collide<float>(a, tau, o, rho, ux, uy);
+        const int j = j0 + v;
+        const bool far = (j == 0) || (j == g.ny - 1);
+#pragma unroll
+        for (int k = 0; k < 9; k++) G[k].v[v] = far ? feq0[k] : o[k];
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_step2p(const float *__restrict__ fs, float *__restrict__ fd, Geom g, int ca, int cb, int nwin, float tau, float U0, int rev)
+{
+    const int lane = threadIdx.x & 63;
+    const int nchunk = (cb - ca + L - 1) / L;
+    long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nunits = (long)nchunk * nwin;
+    if (unit >= nunits) return;
+    if (rev) unit = nunits - 1 - unit;
+    const int q = (int)(unit / nwin), w = (int)(unit % nwin);
+    const int ia = ca + q * L, ib = min(ia + L, cb);
+    const int j0 = w * 252 + lane * 4;
+    const float *s = fs + g.pitch;
+    float *d = fd + g.pitch;
+    const long P = g.plane;
+    float feq0[9];
+    feq_all<float>(1.0f, U0, 0.0f, feq0);
+    const bool first_win = (w == 0);
+
+    V4 G158m[3], G024c[3], G158c[3];      // what step 2 still needs from columns c-1 and c
+    V4 in[9], G[9];
+    load_inputs(s, g, P, ia - 1, j0, in);
+    collide_column(in, g, j0, tau, feq0, G);
+    G158m[0] = G[1]; G158m[1] = G[5]; G158m[2] = G[8];
+    load_inputs(s, g, P, ia, j0, in);
+    collide_column(in, g, j0, tau, feq0, G);
+    G024c[0] = G[0]; G024c[1] = G[2]; G024c[2] = G[4];
+    G158c[0] = G[1]; G158c[1] = G[5]; G158c[2] = G[8];
+    load_inputs(s, g, P, ia + 1, j0, in);                 // in flight while nothing else to do yet
+#pragma unroll 1
+    for (int c = ia; c < ib; c++) {
+        V4 nxt[9];
+        const int cn = (c + 2 <= ib) ? c + 2 : c + 1;      // last iteration: harmless re-load
+        load_inputs(s, g, P, cn, j0, nxt);                 // prefetch for the NEXT iteration
+        collide_column(in, g, j0, tau, feq0, G);           // step 1 of column c+1
+        V4 fin[9];
+        fin[0] = G024c[0]; fin[1] = G158m[0]; fin[3] = G[3];
+        fin[2] = from_below(G024c[1]); fin[5] = from_below(G158m[1]); fin[6] = from_below(G[6]);
+        fin[4] = from_above(G024c[2]); fin[8] = from_above(G158m[2]); fin[7] = from_above(G[7]);
+        V4 out[9];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            float a[9], o[9], rho, ux, uy;
+#pragma unroll
+            for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+            collide<float>(a, tau, o, rho, ux, uy);
+            const int j = j0 + v;
+            const bool far = (j == 0) || (j == g.ny - 1);
+#pragma unroll
+            for (int k = 0; k < 9; k++) out[k].v[v] = far ? feq0[k] : o[k];
+        }
+        const long cc = (long)c * g.pitch + j0;
+        if (j0 + 3 < g.ny) {
+            if (lane == 0 && !first_win) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(d + k * P + cc + 2) = make_float2(out[k].v[2], out[k].v[3]);
+            } else if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(d + k * P + cc) = make_float2(out[k].v[0], out[k].v[1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; k++) vstore<float>(d + k * P + cc, out[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) G158m[k] = G158c[k];
+        G024c[0] = G[0]; G024c[1] = G[2]; G024c[2] = G[4];
+        G158c[0] = G[1]; G158c[1] = G[5]; G158c[2] = G[8];
+#pragma unroll
+        for (int k = 0; k < 9; k++) in[k] = nxt[k];
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const int nx = argc > 1 ? atoi(argv[1]) : 4096, ny = argc > 2 ? atoi(argv[2]) : 4096, rounds = argc > 3 ? atoi(argv[3]) : 10;
+    Geom g; g.nxl = nx; g.ny = ny; g.gi0 = 0; g.nx_g = nx; g.pitch = ((long)ny + 255) / 256 * 256;
+    g.plane = (((long)(nx + 2) * g.pitch * 4 + 4095) / 4096 * 4096 + 17408) / 4;
+    const int tpc = (int)(g.pitch / 256);
+    const size_t lat = (size_t)9 * g.plane * 4;
+    float *f0, *f1, *f2, *f3, *macro; uint8_t *mask, *tiles;
+    CK(hipMalloc(&f0, lat)); CK(hipMalloc(&f1, lat)); CK(hipMalloc(&f2, lat)); CK(hipMalloc(&f3, lat));
+    CK(hipMalloc(&macro, (size_t)3 * nx * g.pitch * 4));
+    CK(hipMalloc(&mask, (size_t)(nx + 2) * g.pitch)); CK(hipMalloc(&tiles, (size_t)nx * tpc));
+    CK(hipMemset(mask, 0, (size_t)(nx + 2) * g.pitch));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    classify_tiles(mask, tiles, g, tpc, st);
+    // non-trivial initial state: pseudo-random perturbation of the equilibrium
+    {
+        std::vector<float> h((size_t)9 * g.plane);
+        const double u0 = 0.06;
+        unsigned long long x = 88172645463325252ULL;
+        for (int k = 0; k < 9; k++) {
+            const double wgt = k == 0 ? 4.0 / 9 : (k <= 4 ? 1.0 / 9 : 1.0 / 36); const double eu = ex_of(k) * u0;
+            const float base = (float)(wgt * (1 + 3 * eu + 4.5 * eu * eu - 1.5 * u0 * u0));
+            for (long t = 0; t < g.plane; t++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[(size_t)k * g.plane + t] = base * (1.0f + 0.02f * ((x >> 40) / 16777216.0f - 0.5f)); }
+        }
+        CK(hipMemcpy(f0, h.data(), lat, hipMemcpyHostToDevice));
+    }
+    const float tau = 0.58f, U0 = 0.06f;
+    // reference: two production steps f0 -> f1 -> f2
+    step_columns<float, 3>(f0, f1, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 0, st);
+    step_columns<float, 3>(f1, f2, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 1, st);
+    CK(hipStreamSynchronize(st));
+    const int ca = 2, cb = nx - 2, nwin = (ny - 2 + 251) / 252;
+    auto launch2 = [&](auto kern, int L, const float *a, float *b, int rev) {
+        const int nchunk = (cb - ca + L - 1) / L;
+        const long nunits = (long)nchunk * nwin;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, a, b, g, ca, cb, nwin, tau, U0, rev);
+    };
+    CK(hipMemset(f3, 0, lat));
+    launch2(k_step2p<16>, 16, f0, f3, 0);
+    CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+    {
+        std::vector<float> a((size_t)g.plane), b((size_t)g.plane);
+        long bad = 0, checked = 0;
+        for (int k = 0; k < 9; k++) {
+            CK(hipMemcpy(a.data(), f2 + (size_t)k * g.plane, g.plane * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), f3 + (size_t)k * g.plane, g.plane * 4, hipMemcpyDeviceToHost));
+            for (int i = ca; i < cb; i++) for (int j = 0; j < ny; j++) {
+                const size_t o = (size_t)(i + 1) * g.pitch + j;
+                checked++;
+                if (memcmp(&a[o], &b[o], 4) != 0) { if (bad < 5) printf("mismatch k=%d i=%d j=%d: %g vs %g\n", k, i, j, a[o], b[o]); bad++; }
+            }
+        }
+        printf("fused vs 2x production: %ld / %ld values differ\n", bad, checked);
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    struct Var { std::string name; std::function<void(const float *, float *, int)> fn; std::vector<float> ms; int steps; };
+    std::vector<Var> vs;
+    vs.push_back({"production, 2 launches", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, f1, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(f1, b, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
+    vs.push_back({"fused L=8", [&](const float *a, float *b, int r) { launch2(k_step2<8>, 8, a, b, r); }, {}, 2});
+    vs.push_back({"fused L=16", [&](const float *a, float *b, int r) { launch2(k_step2<16>, 16, a, b, r); }, {}, 2});
+    vs.push_back({"fused L=32", [&](const float *a, float *b, int r) { launch2(k_step2<32>, 32, a, b, r); }, {}, 2});
+    vs.push_back({"fused+prefetch L=8", [&](const float *a, float *b, int r) { launch2(k_step2p<8>, 8, a, b, r); }, {}, 2});
+    vs.push_back({"fused+prefetch L=12", [&](const float *a, float *b, int r) { launch2(k_step2p<12>, 12, a, b, r); }, {}, 2});
+    vs.push_back({"fused+prefetch L=16", [&](const float *a, float *b, int r) { launch2(k_step2p<16>, 16, a, b, r); }, {}, 2});
+    vs.push_back({"fused+prefetch L=24", [&](const float *a, float *b, int r) { launch2(k_step2p<24>, 24, a, b, r); }, {}, 2});
+    vs.push_back({"fused+prefetch L=32", [&](const float *a, float *b, int r) { launch2(k_step2p<32>, 32, a, b, r); }, {}, 2});
+    const int reps = 4;
+    for (int r = 0; r < rounds + 2; r++)
+        for (auto &v : vs) {
+            CK(hipEventRecord(e0, st));
+            for (int q = 0; q < reps; q++) { if (q & 1) v.fn(f3, f0, 1); else v.fn(f0, f3, 0); }
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) v.ms.push_back(ms / reps / v.steps);
+        }
+    printf("%-28s %12s %12s %10s\n", "variant", "us per STEP", "min", "GLUPS");
+    for (auto &v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        const double med = v.ms[v.ms.size() / 2];
+        printf("%-28s %12.1f %12.1f %10.1f\n", v.name.c_str(), med * 1e3, v.ms[0] * 1e3, (double)nx * ny / (med * 1e-3) / 1e9);
+    }
+    return 0;
+}
