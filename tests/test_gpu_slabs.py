@@ -117,3 +117,29 @@ def test_slab_fields_equal_single_lattice(pkg):
     finally:
         for e in es:
             e.close()
+
+
+def test_slab_wind_tunnel_with_real_engine_world1(pkg, oracle_c):
+    """The torch.distributed host class (SlabWindTunnel) over the real engine, world_size 1 (gloo
+    group created in-process): same results as WindTunnel / the oracle."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from airfoil_cfd_tool_amd.distributed import SlabWindTunnel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with SlabWindTunnel(shape="naca2412", nx=512, ny=256, aoa_deg=6.0, device=0) as wt:
+            for _ in range(6):
+                wt.frame()
+            rho, ux, uy = wt.read_macro()
+            f = wt.read_f()
+            t = wt.render_field("vort")
+            fr, mr = oracle_c.run(wt.geometry.mask, 24, 0.58, 0.06, np.float32)
+            assert bits_equal(f, fr) and bits_equal(rho, mr[0]) and bits_equal(ux, mr[1]) and bits_equal(uy, mr[2])
+            assert t.shape == (256, 512) and wt.stats().cl is not None
+    finally:
+        dist.destroy_process_group()

@@ -225,6 +225,149 @@ __global__ __launch_bounds__(256) void k_step2p(const float *__restrict__ fs, fl
     }
 }
 
+// ---- generic variant: NS sites per lane (4 or 2), optional dynamic unit queue ---------------------
+template <int NS> struct VecN { float v[NS]; };
+template <int NS> __device__ __forceinline__ VecN<NS> ldv(const float *p, bool unaligned)
+{
+    typedef float VA __attribute__((ext_vector_type(NS)));
+    typedef float VU __attribute__((ext_vector_type(NS), aligned(4)));
+    VecN<NS> r;
+    if (unaligned) { const VU x = __builtin_nontemporal_load(reinterpret_cast<const VU *>(p));
+#pragma unroll
+        for (int v = 0; v < NS; v++) r.v[v] = x[v]; }
+    else { const VA x = __builtin_nontemporal_load(reinterpret_cast<const VA *>(p));
+#pragma unroll
+        for (int v = 0; v < NS; v++) r.v[v] = x[v]; }
+    return r;
+}
+template <int NS> __device__ __forceinline__ void stv(float *p, const VecN<NS> &r)
+{
+    typedef float VA __attribute__((ext_vector_type(NS)));
+    VA x;
+#pragma unroll
+    for (int v = 0; v < NS; v++) x[v] = r.v[v];
+    *reinterpret_cast<VA *>(p) = x;
+}
+template <int NS> __device__ __forceinline__ void load9(const float *__restrict__ s, const Geom &g, long P, int col, int j0, VecN<NS> (&fin)[9])
+{
+    const long c = (long)col * g.pitch + j0;
+    fin[0] = ldv<NS>(s + 0 * P + c, false);
+    fin[1] = ldv<NS>(s + 1 * P + c - g.pitch, false);
+    fin[3] = ldv<NS>(s + 3 * P + c + g.pitch, false);
+    fin[2] = ldv<NS>(s + 2 * P + c - 1, true);
+    fin[5] = ldv<NS>(s + 5 * P + c - g.pitch - 1, true);
+    fin[6] = ldv<NS>(s + 6 * P + c + g.pitch - 1, true);
+    fin[4] = ldv<NS>(s + 4 * P + c + 1, true);
+    fin[7] = ldv<NS>(s + 7 * P + c + g.pitch + 1, true);
+    fin[8] = ldv<NS>(s + 8 * P + c - g.pitch + 1, true);
+}
+template <int NS> __device__ __forceinline__ void collideN(const VecN<NS> (&fin)[9], const Geom &g, int j0, float tau, const float (&feq0)[9], VecN<NS> (&G)[9])
+{
+#pragma unroll
+    for (int v = 0; v < NS; v++) {
+        float a[9], o[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+        collide<float>(a, tau, o, rho, ux, uy);
+        const int j = j0 + v;
+        const bool far = (j == 0) || (j == g.ny - 1);
+#pragma unroll
+        for (int k = 0; k < 9; k++) G[k].v[v] = far ? feq0[k] : o[k];
+    }
+}
+template <int NS> __device__ __forceinline__ VecN<NS> belowN(const VecN<NS> &r)
+{
+    VecN<NS> o; o.v[0] = lane_up(r.v[NS - 1]);
+#pragma unroll
+    for (int v = 1; v < NS; v++) o.v[v] = r.v[v - 1];
+    return o;
+}
+template <int NS> __device__ __forceinline__ VecN<NS> aboveN(const VecN<NS> &r)
+{
+    VecN<NS> o;
+#pragma unroll
+    for (int v = 0; v < NS - 1; v++) o.v[v] = r.v[v + 1];
+    o.v[NS - 1] = lane_down(r.v[0]);
+    return o;
+}
+
+// QUEUE: units are taken from a global atomic counter by persistent waves (grid = resident capacity)
+template <int NS, bool QUEUE, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ fs, float *__restrict__ fd, Geom g, int ca, int cb, int L, int nwin,
+                                                      float tau, float U0, int rev, unsigned int *__restrict__ counter)
+{
+    constexpr int WS = 64 * NS - 4;             // rows a window advances by
+    const int lane = threadIdx.x & 63;
+    const int nchunk = (cb - ca + L - 1) / L;
+    const long nunits = (long)nchunk * nwin;
+    const float *s = fs + g.pitch;
+    float *d = fd + g.pitch;
+    const long P = g.plane;
+    float feq0[9];
+    feq_all<float>(1.0f, U0, 0.0f, feq0);
+    long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (;;) {
+        if (QUEUE) {
+            unsigned int u = 0;
+            if (lane == 0) u = atomicAdd(counter, 1u);
+            unit = __builtin_amdgcn_readfirstlane(u);
+        }
+        if (unit >= nunits) return;
+        const long uu = rev ? nunits - 1 - unit : unit;
+        const int q = (int)(uu / nwin), w = (int)(uu % nwin);
+        const int ia = ca + q * L, ib = min(ia + L, cb);
+        const int j0 = w * WS + lane * NS;
+        const bool first_win = (w == 0);
+        VecN<NS> G158m[3], G024c[3], G158c[3], in[9], G[9];
+        load9<NS>(s, g, P, ia - 1, j0, in);
+        collideN<NS>(in, g, j0, tau, feq0, G);
+        G158m[0] = G[1]; G158m[1] = G[5]; G158m[2] = G[8];
+        load9<NS>(s, g, P, ia, j0, in);
+        collideN<NS>(in, g, j0, tau, feq0, G);
+        G024c[0] = G[0]; G024c[1] = G[2]; G024c[2] = G[4];
+        G158c[0] = G[1]; G158c[1] = G[5]; G158c[2] = G[8];
+        load9<NS>(s, g, P, ia + 1, j0, in);
+#pragma unroll 1
+        for (int c = ia; c < ib; c++) {
+            VecN<NS> nxt[9];
+            load9<NS>(s, g, P, (c + 2 <= ib) ? c + 2 : c + 1, j0, nxt);
+            collideN<NS>(in, g, j0, tau, feq0, G);
+            VecN<NS> fin[9], out[9];
+            fin[0] = G024c[0]; fin[1] = G158m[0]; fin[3] = G[3];
+            fin[2] = belowN<NS>(G024c[1]); fin[5] = belowN<NS>(G158m[1]); fin[6] = belowN<NS>(G[6]);
+            fin[4] = aboveN<NS>(G024c[2]); fin[8] = aboveN<NS>(G158m[2]); fin[7] = aboveN<NS>(G[7]);
+            collideN<NS>(fin, g, j0, tau, feq0, out);
+            const long cc = (long)c * g.pitch + j0;
+            if (j0 + NS - 1 < g.ny) {
+                if (NS == 4) {
+                    if (lane == 0 && !first_win) {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(d + k * P + cc + 2) = make_float2(out[k].v[NS - 2], out[k].v[NS - 1]);
+                    } else if (lane == 63) {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(d + k * P + cc) = make_float2(out[k].v[0], out[k].v[1]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) stv<NS>(d + k * P + cc, out[k]);
+                    }
+                } else {   // NS == 2: lane 0 (unless first window) and lane 63 produce nothing
+                    if (!((lane == 0 && !first_win) || lane == 63)) {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) stv<NS>(d + k * P + cc, out[k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) G158m[k] = G158c[k];
+            G024c[0] = G[0]; G024c[1] = G[2]; G024c[2] = G[4];
+            G158c[0] = G[1]; G158c[1] = G[5]; G158c[2] = G[8];
+#pragma unroll
+            for (int k = 0; k < 9; k++) in[k] = nxt[k];
+        }
+        if (!QUEUE) return;
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int nx = argc > 1 ? atoi(argv[1]) : 4096, ny = argc > 2 ? atoi(argv[2]) : 4096, rounds = argc > 3 ? atoi(argv[3]) : 10;
@@ -279,7 +422,31 @@ int main(int argc, char **argv)
         }
         printf("fused vs 2x production: %ld / %ld values differ\n", bad, checked);
     }
+    unsigned int *counter; CK(hipMalloc(&counter, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto check = [&](const char *name) {
+        std::vector<float> a((size_t)g.plane), b((size_t)g.plane);
+        long bad = 0;
+        for (int k = 0; k < 9; k++) {
+            CK(hipMemcpy(a.data(), f2 + (size_t)k * g.plane, g.plane * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(b.data(), f3 + (size_t)k * g.plane, g.plane * 4, hipMemcpyDeviceToHost));
+            for (int i = ca; i < cb; i++) for (int j = 0; j < ny; j++) { const size_t o = (size_t)(i + 1) * g.pitch + j; if (memcmp(&a[o], &b[o], 4) != 0) bad++; }
+        }
+        printf("check %-22s: %ld values differ\n", name, bad);
+    };
+    {
+        const int L = 12;
+        for (int variant = 0; variant < 2; variant++) {
+            CK(hipMemset(f3, 0, lat)); CK(hipDeviceSynchronize());
+            const int NS = variant == 0 ? 2 : 4; const int WS = 64 * NS - 4; const int nw = (ny - 2 + WS - 1) / WS;
+            const long nunits = (long)((cb - ca + L - 1) / L) * nw;
+            CK(hipMemsetAsync(counter, 0, 4, st));
+            if (variant == 0) hipLaunchKernelGGL((k_step2g<2, true, 1>), dim3(1024), dim3(256), 0, st, f0, f3, g, ca, cb, L, nw, tau, U0, 0, counter);
+            else hipLaunchKernelGGL((k_step2g<4, false, 1>), dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, f0, f3, g, ca, cb, L, nw, tau, U0, 1, counter);
+            CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+            check(variant == 0 ? "NS=2 queue L=12" : "NS=4 static L=12 rev");
+        }
+    }
     struct Var { std::string name; std::function<void(const float *, float *, int)> fn; std::vector<float> ms; int steps; };
     std::vector<Var> vs;
     vs.push_back({"production, 2 launches", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, f1, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(f1, b, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
@@ -291,6 +458,21 @@ int main(int argc, char **argv)
     vs.push_back({"fused+prefetch L=16", [&](const float *a, float *b, int r) { launch2(k_step2p<16>, 16, a, b, r); }, {}, 2});
     vs.push_back({"fused+prefetch L=24", [&](const float *a, float *b, int r) { launch2(k_step2p<24>, 24, a, b, r); }, {}, 2});
     vs.push_back({"fused+prefetch L=32", [&](const float *a, float *b, int r) { launch2(k_step2p<32>, 32, a, b, r); }, {}, 2});
+    auto launchg = [&](auto kern, int NS, bool queue, int L, int wavesPerSimd, const float *a, float *b, int rev) {
+        const int WS = 64 * NS - 4;
+        const int nw = (ny - 2 + WS - 1) / WS;
+        const int nchunk = (cb - ca + L - 1) / L;
+        const long nunits = (long)nchunk * nw;
+        long blocks = (nunits + 3) / 4;
+        if (queue) { CK(hipMemsetAsync(counter, 0, 4, st)); blocks = 256L * wavesPerSimd; if (blocks * 4 > nunits) blocks = (nunits + 3) / 4; }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, a, b, g, ca, cb, L, nw, tau, U0, rev, counter);
+    };
+    for (int L : {8, 12, 16, 24}) {
+        vs.push_back({"g NS=4 static L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1>, 4, false, L, 2, a, b, r); }, {}, 2});
+        vs.push_back({"g NS=4 queue  L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, true, 1>, 4, true, L, 2, a, b, r); }, {}, 2});
+        vs.push_back({"g NS=2 static L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<2, false, 1>, 2, false, L, 4, a, b, r); }, {}, 2});
+        vs.push_back({"g NS=2 queue  L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<2, true, 1>, 2, true, L, 4, a, b, r); }, {}, 2});
+    }
     const int reps = 4;
     for (int r = 0; r < rounds + 2; r++)
         for (auto &v : vs) {
