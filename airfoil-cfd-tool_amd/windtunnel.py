@@ -95,7 +95,7 @@ class WindTunnel:
         self.tau = float(tau) if tau is not None else (tau_from_reynolds(re, self.u0, self.nx) if re is not None else TAU_DEFAULT)
         self.field = field
         self.y_half = y_half
-        self.engine = Engine(self.nx, self.ny, dtype=dtype, device=device)
+        self.engine = self._make_engine(dtype, device)
         self.dtype = self.engine.dtype
         # html:593 initial ranges, html:641 force state, html:594 frame counter
         self.max_s, self.cp_min, self.cp_max = 0.6, -1.0, 1.0
@@ -109,6 +109,16 @@ class WindTunnel:
         self.parser_fixes: list = []
         self.init_sim(self.u0)                                   # html:502-504
         self.apply_geometry(aoa_deg)                             # html:969-970
+
+    # ---- hooks the sharded subclass (distributed.SlabWindTunnel) overrides ----------------
+    def _make_engine(self, dtype, device):
+        return Engine(self.nx, self.ny, dtype=dtype, device=device)
+
+    def _reduce_ranges(self):
+        return self.engine.reduce_ranges(self.u0)
+
+    def _forces(self):
+        return self.engine.forces()
 
     @classmethod
     def from_dat(cls, dat_path: str, name: Optional[str] = None, **kwargs) -> "WindTunnel":
@@ -162,7 +172,7 @@ class WindTunnel:
 
     def update_fields_from_macro(self):
         """updateFieldsFromMacro's range scan (html:596-614) incl. 'keep previous' (611-613)."""
-        mx, cmin, cmax = self.engine.reduce_ranges(self.u0)
+        mx, cmin, cmax = self._reduce_ranges()
         if mx > 0:
             self.max_s = mx
         if math.isfinite(cmin):
@@ -174,7 +184,7 @@ class WindTunnel:
     def compute_forces(self):
         """computeForces (html:650-700): pressure force on the staircase body and
         separation fraction, with the reference's exponential smoothing."""
-        fx, fy, surf, rev = self.engine.forces()
+        fx, fy, surf, rev = self._forces()
         if surf == 0:                                   # `if(!any) return;`
             return None
         q = 0.5 * self.u0 * self.u0 * chord_cells(self.nx)

@@ -32,7 +32,7 @@ def main():
     wt.compute_forces()
     macro = wt.read_macro()
     f = wt.read_f()
-    t_speed = wt.render_field("speed")
+    t_speed = wt.render_field(field="speed")
     ok = True
     if rank == 0:
         import airfoil_cfd_tool_amd.geometry as geo

@@ -137,7 +137,8 @@ def test_slab_wind_tunnel_with_real_engine_world1(pkg, oracle_c):
                 wt.frame()
             rho, ux, uy = wt.read_macro()
             f = wt.read_f()
-            t = wt.render_field("vort")
+            t = wt.render_field(field="vort")
+            assert wt.render_rgba().shape == (256, 512, 4)
             fr, mr = oracle_c.run(wt.geometry.mask, 24, 0.58, 0.06, np.float32)
             assert bits_equal(f, fr) and bits_equal(rho, mr[0]) and bits_equal(ux, mr[1]) and bits_equal(uy, mr[2])
             assert t.shape == (256, 512) and wt.stats().cl is not None
