@@ -80,6 +80,15 @@ def cpu_baseline(mask, steps, tau, u0, dtype):
     }
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as fh:
+            return json.load(fh)["metric"]
+    except Exception:
+        return "MLUPS on 4096\u00b2 fp32 D2Q9 at 1/2/4/8 MI355X; achieved % HBM3E peak"
+
+
 def measured_traffic(workload_key):
     """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (None if absent)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -166,7 +175,7 @@ def main():
     workload = (f"{args.shape.upper()} {nx_total}x{ny} {args.dtype} D2Q9, AoA={args.aoa:g} deg, U0={args.u0:g}, "
                 f"tau={args.tau:g} (BASELINE configs[2]; S1223 coordinates unavailable offline -> NACA 6409)")
     out = {
-        "metric": "MLUPS on 4096^2 fp32 D2Q9 at 1/2/4/8 MI355X; achieved % HBM3E peak",
+        "metric": baseline_metric(),
         "value": mlups,
         "unit": "MLUPS",
         "n_gpus": world,
