@@ -12,7 +12,7 @@ all: lib oracle
 
 lib: $(LIB)
 
-$(LIB): $(CSRC)/windtunnel.hip $(CSRC)/kernels.hpp $(CSRC)/step_fast.hpp $(CSRC)/d2q9.hpp include/windtunnel.h
+$(LIB): $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.hpp) include/windtunnel.h
 	mkdir -p $(PKG)/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/windtunnel.hip $(LDFLAGS)
 

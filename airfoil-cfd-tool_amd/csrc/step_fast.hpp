@@ -30,15 +30,17 @@ static inline int tile_j_of(size_t esz) { return esz == 4 ? 256 : 128; }
 // --------------------------------------------------------------------------------------------
 // tile classification: one wave per tile
 // --------------------------------------------------------------------------------------------
+// tiles are `tj` rows tall and start every `stride` rows (stride = tj for the step kernel's own grid;
+// 252-row stride / 256-row height for the window-aligned grid of the two-step mode, step_fused.hpp)
 __global__ __launch_bounds__(256) void k_classify(const uint8_t *__restrict__ mask, uint8_t *__restrict__ tiles, Geom g,
-                                                  int tiles_per_col, int tj)
+                                                  int tiles_per_col, int tj, int stride)
 {
     const int lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long ntiles = (long)g.nxl * tiles_per_col;
     if (tile >= ntiles) return;
     const int i = (int)(tile / tiles_per_col), jt = (int)(tile % tiles_per_col);
-    const int j0 = jt * tj;
+    const int j0 = jt * stride;
     const uint8_t *m = mask + g.pitch;
     int nb = 0, own_any = 0, own_all = 1;
     for (int jj = j0 - 1 + lane; jj <= j0 + tj; jj += 64) {
@@ -62,11 +64,13 @@ __global__ __launch_bounds__(256) void k_classify(const uint8_t *__restrict__ ma
     if (lane == 0) tiles[tile] = cls;
 }
 
-static inline int classify_tiles(const uint8_t *mask, uint8_t *tiles, const Geom &g, int tiles_per_col, hipStream_t st)
+static inline int classify_tiles(const uint8_t *mask, uint8_t *tiles, const Geom &g, int tiles_per_col, hipStream_t st,
+                                 int tj = 0, int stride = 0)
 {
-    const int tj = (int)(g.pitch / tiles_per_col);
+    if (tj == 0) tj = (int)(g.pitch / tiles_per_col);
+    if (stride == 0) stride = tj;
     const long ntiles = (long)g.nxl * tiles_per_col;
-    hipLaunchKernelGGL(k_classify, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, mask, tiles, g, tiles_per_col, tj);
+    hipLaunchKernelGGL(k_classify, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, mask, tiles, g, tiles_per_col, tj, stride);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -148,10 +152,13 @@ __device__ __forceinline__ Vec<T> shift_from_above(const Vec<T> &r, const T *p, 
 // with element-aligned 16-B loads instead of aligned loads + lane shuffles.
 // rev: walk the tiles backwards.  Successive steps alternate the direction so that a step starts
 // by reading what the previous step wrote last — still resident in the 256 MB Infinity Cache.
-template <typename T, bool EMIT, int LOADMODE>
+// WIN: the tile belongs to a grid whose tiles start every `stride` rows (tile height stays 64*N) and
+// only rows in [st_lo, st_hi) are stored — the window-aligned zone passes of step_fused.hpp.
+template <typename T, bool EMIT, int LOADMODE, bool WIN = false>
 __device__ __forceinline__ void step_tile(const T *__restrict__ fs, T *__restrict__ fd, T *__restrict__ macro,
                                           const uint8_t *__restrict__ mask, const uint8_t *__restrict__ tiles,
-                                          int tiles_per_col, const Geom &g, int i_begin, T tau, T U0, long tile_local, int lane)
+                                          int tiles_per_col, const Geom &g, int i_begin, T tau, T U0, long tile_local, int lane,
+                                          int stride = 0, int st_lo = 0, int st_hi = 0)
 {
     constexpr int N = VecOf<T>::N;
     constexpr int TJ = 64 * N;
@@ -159,6 +166,7 @@ __device__ __forceinline__ void step_tile(const T *__restrict__ fs, T *__restric
     constexpr bool UNALIGNED = (LOADMODE & 2) != 0;
     const int i = i_begin + (int)(tile_local / tiles_per_col);
     const int jt = (int)(tile_local % tiles_per_col);
+    const int row0 = WIN ? jt * stride : jt * TJ;
     const int cls = __builtin_amdgcn_readfirstlane((int)tiles[(long)i * tiles_per_col + jt]);
     const T *s = fs + g.pitch;
     T *d = fd + g.pitch;
@@ -169,13 +177,13 @@ __device__ __forceinline__ void step_tile(const T *__restrict__ fs, T *__restric
         const uint8_t *m = mask + g.pitch;
 #pragma unroll 1
         for (int v = 0; v < N; v++) {
-            const int j = jt * TJ + v * 64 + lane;
-            if (j < g.ny) site_general<T>(s, d, macro, m, g, i, j, tau, U0, EMIT);
+            const int j = row0 + v * 64 + lane;
+            if (j < g.ny && (!WIN || (j >= st_lo && j < st_hi))) site_general<T>(s, d, macro, m, g, i, j, tau, U0, EMIT);
         }
         return;
     }
 
-    const int j0 = jt * TJ + lane * N;
+    const int j0 = row0 + lane * N;
     const long c = (long)i * g.pitch + j0;
     Vec<T> out[9];
     Vec<T> mrho, mux, muy;
@@ -242,6 +250,19 @@ __device__ __forceinline__ void step_tile(const T *__restrict__ fs, T *__restric
             mrho.v[v] = rho;
             mux.v[v] = (q1 + q5 + q8 - q3 - q6 - q7) / rho;
             muy.v[v] = (q2 + q5 + q6 - q4 - q7 - q8) / rho;
+        }
+    }
+    if constexpr (WIN) {
+        if (j0 < st_lo || j0 + N > st_hi) {        // window edge lanes: store only the rows inside [st_lo, st_hi)
+#pragma unroll
+            for (int v = 0; v < N; v++) {
+                const int j = j0 + v;
+                if (j < st_lo || j >= st_hi) continue;
+#pragma unroll
+                for (int k = 0; k < 9; k++) d[k * P + c + v] = out[k].v[v];
+                if (EMIT) { macro[c + v] = mrho.v[v]; macro[mp + c + v] = mux.v[v]; macro[2 * mp + c + v] = muy.v[v]; }
+            }
+            return;
         }
     }
 #pragma unroll

@@ -156,18 +156,26 @@ __global__ __launch_bounds__(256) void k_step2(const float *__restrict__ fs, flo
     }
 }
 
-// single-step kernel over an explicit tile list (the non-fusable zone)
-template <typename T, bool EMIT, int LOADMODE>
+// Single-step kernel over a list of WINDOW-ALIGNED tiles (column x, window w): rows
+// [252w, 252w+256) are computed; PASS 1 (A -> C) stores all of them, PASS 2 (C -> B) stores the
+// window's own output rows [252w+2, 252w+254) (to the domain edge for the first / last window), whose
+// stencil stays inside the rows pass 1 produced — no ring of extra tiles above or below the zone.
+template <typename T, bool EMIT, int LOADMODE, int PASS>
 __global__ __launch_bounds__(256) void k_step_list(const T *__restrict__ fs, T *__restrict__ fd, T *__restrict__ macro,
-                                                   const uint8_t *__restrict__ mask, const uint8_t *__restrict__ tiles,
-                                                   int tiles_per_col, Geom g, const int *__restrict__ list, int nlist, T tau, T U0, int rev)
+                                                   const uint8_t *__restrict__ mask, const uint8_t *__restrict__ wtiles,
+                                                   int nwin, Geom g, const int *__restrict__ list, int nlist, T tau, T U0, int rev)
 {
     const int lane = threadIdx.x & 63;
     int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= nlist) return;
     if (rev) t = nlist - 1 - t;
-    const long tile = __builtin_amdgcn_readfirstlane(list[t]);
-    step_tile<T, EMIT, LOADMODE>(fs, fd, macro, mask, tiles, tiles_per_col, g, 0, tau, U0, tile, lane);
+    const int tile = __builtin_amdgcn_readfirstlane(list[t]);
+    const int w = tile % nwin;
+    const int row0 = w * FUSE_WIN_STRIDE;
+    int lo, hi;
+    if (PASS == 1) { lo = row0; hi = row0 + 256; }
+    else { lo = (w == 0) ? 0 : row0 + 2; hi = (w == nwin - 1) ? g.ny : row0 + 254; }
+    step_tile<T, EMIT, LOADMODE, true>(fs, fd, macro, mask, wtiles, nwin, g, 0, tau, U0, tile, lane, FUSE_WIN_STRIDE, lo, hi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -175,39 +183,77 @@ __global__ __launch_bounds__(256) void k_step_list(const T *__restrict__ fs, T *
 // ------------------------------------------------------------------------------------------------
 struct FusePlan {
     std::vector<FuseUnit> units;     // fusable units, chunk-major
-    std::vector<int> t1, t2;         // tile ids (i*tiles_per_col + jt) of pass 1 (A->C) and pass 2 (C->B)
-    int chunk = 0;
+    std::vector<int> t1, t2;         // window-tile ids (x*nwin + w) of pass 1 (A->C) and pass 2 (C->B)
+    int chunk = 0, nwin = 0;
     bool usable = false;
 };
 
-// mask: host [NY][NX] (non-zero = solid).  Whole-lattice fp32 handles with NY % 4 == 0 only.
-static inline FusePlan build_fuse_plan(const uint8_t *mask, int nx, int ny, int tiles_per_col, int L)
-{
-    FusePlan p;
-    p.chunk = L;
-    if (ny % 4 != 0 || nx < 8 || ny < 8 || L < 1) return p;
-    const int tpc = tiles_per_col;
-    // solid flag per 256-row tile of every column, with 2-D inclusive prefix sums
-    std::vector<int> pre((size_t)(nx + 1) * (tpc + 1), 0);
-    {
-        std::vector<uint8_t> flag((size_t)nx * tpc, 0);
-        for (int y = 0; y < ny; y++) {
-            const uint8_t *row = mask + (size_t)y * nx;
-            const int jt = y / 256;
-            for (int x = 0; x < nx; x++) if (row[x]) flag[(size_t)x * tpc + jt] = 1;
-        }
-        for (int x = 0; x < nx; x++)
-            for (int t = 0; t < tpc; t++)
-                pre[(size_t)(x + 1) * (tpc + 1) + t + 1] = flag[(size_t)x * tpc + t] + pre[(size_t)x * (tpc + 1) + t + 1] +
-                                                           pre[(size_t)(x + 1) * (tpc + 1) + t] - pre[(size_t)x * (tpc + 1) + t];
-    }
-    auto any_solid = [&](int x0, int x1, int t0, int t1) {   // columns [x0,x1), tiles [t0,t1]
+// 2-D prefix sums of "column x has a solid site in rows [256t, 256t+256)" — one scan of the mask
+struct FuseScan {
+    int nx = 0, ny = 0, tpc = 0;
+    std::vector<int> pre;
+    bool any_solid(int x0, int x1, int t0, int t1) const {      // columns [x0,x1), 256-row tiles [t0,t1]
         x0 = x0 < 0 ? 0 : x0; x1 = x1 > nx ? nx : x1; t0 = t0 < 0 ? 0 : t0; t1 = t1 > tpc - 1 ? tpc - 1 : t1;
         if (x1 <= x0 || t1 < t0) return false;
         const long s = (long)pre[(size_t)x1 * (tpc + 1) + t1 + 1] - pre[(size_t)x0 * (tpc + 1) + t1 + 1] -
                        pre[(size_t)x1 * (tpc + 1) + t0] + pre[(size_t)x0 * (tpc + 1) + t0];
         return s != 0;
-    };
+    }
+    bool unit_fusable(int ia, int ib, int w) const {            // input footprint: columns [ia-2, ib+2), rows [J0-1, J0+257)
+        const int J0 = w * FUSE_WIN_STRIDE;
+        return !any_solid(ia - 2, ib + 2, (J0 - 1 < 0 ? 0 : J0 - 1) / 256, (J0 + 256) / 256);
+    }
+};
+
+// mask: host [NY][NX] (non-zero = solid)
+static inline FuseScan scan_mask(const uint8_t *mask, int nx, int ny)
+{
+    FuseScan sc;
+    sc.nx = nx; sc.ny = ny; sc.tpc = (ny + 255) / 256;
+    const int tpc = sc.tpc;
+    sc.pre.assign((size_t)(nx + 1) * (tpc + 1), 0);
+    std::vector<uint8_t> flag((size_t)nx * tpc, 0);
+    for (int y = 0; y < ny; y++) {
+        const uint8_t *row = mask + (size_t)y * nx;
+        const int jt = y / 256;
+        for (int x = 0; x < nx; x++) if (row[x]) flag[(size_t)x * tpc + jt] = 1;
+    }
+    for (int x = 0; x < nx; x++)
+        for (int t = 0; t < tpc; t++)
+            sc.pre[(size_t)(x + 1) * (tpc + 1) + t + 1] = flag[(size_t)x * tpc + t] + sc.pre[(size_t)x * (tpc + 1) + t + 1] +
+                                                          sc.pre[(size_t)(x + 1) * (tpc + 1) + t] - sc.pre[(size_t)x * (tpc + 1) + t];
+    return sc;
+}
+
+// Chunk length for a chip that keeps `capacity` fused waves resident (2 per SIMD).  Units are
+// equal-sized and the dispatcher refills free slots, so the kernel takes about
+//   units * (L+2) / capacity   (work, incl. the 2 redundant step-1 columns per chunk)
+// + (L+2) / 2                  (ragged end: half a unit on average)
+// column iterations; measured optimum on the 4096^2 bench body: L = 16 (tools/kfuse, bench --fuse-chunk).
+static inline int auto_fuse_chunk(const FuseScan &sc, long capacity)
+{
+    const int ca = 2, cb = sc.nx - 2;
+    const int nwin = (sc.ny - 2 + FUSE_WIN_STRIDE - 1) / FUSE_WIN_STRIDE;
+    int best_L = 16;
+    double best = 1e300;
+    for (int L = 6; L <= 64; L++) {
+        long units = 0;
+        for (int ia = ca; ia < cb; ia += L)
+            for (int w = 0; w < nwin; w++) units += sc.unit_fusable(ia, (ia + L < cb) ? ia + L : cb, w);
+        if (units == 0) continue;
+        const double cost = (double)units * (L + 2) / (double)capacity + 0.5 * (L + 2);
+        if (cost < best) { best = cost; best_L = L; }
+    }
+    return best_L;
+}
+
+// Whole-lattice fp32 handles with NY % 4 == 0 only.
+static inline FusePlan build_fuse_plan(const FuseScan &sc, int L)
+{
+    FusePlan p;
+    p.chunk = L;
+    const int nx = sc.nx, ny = sc.ny;
+    if (ny % 4 != 0 || nx < 8 || ny < 8 || L < 1) return p;
     const int ca = 2, cb = nx - 2;
     const int nwin = (ny - 2 + FUSE_WIN_STRIDE - 1) / FUSE_WIN_STRIDE;
     const int nchunk = (cb - ca + L - 1) / L;
@@ -215,41 +261,31 @@ static inline FusePlan build_fuse_plan(const uint8_t *mask, int nx, int ny, int 
     for (int q = 0; q < nchunk; q++) {
         const int ia = ca + q * L, ib = (ia + L < cb) ? ia + L : cb;
         for (int w = 0; w < nwin; w++) {
-            const int J0 = w * FUSE_WIN_STRIDE;
-            // input footprint: columns [ia-2, ib+2), rows [J0-1, J0+257)
-            const bool ok = !any_solid(ia - 2, ib + 2, (J0 - 1 < 0 ? 0 : J0 - 1) / 256, (J0 + 256) / 256);
+            const bool ok = sc.unit_fusable(ia, ib, w);
             fus[(size_t)q * nwin + w] = ok;
             if (ok) p.units.push_back(FuseUnit{ia, ib, w, 0});
         }
     }
-    auto window_of_row = [&](int r) { int w = r < 254 ? 0 : (r - 2) / FUSE_WIN_STRIDE; return w > nwin - 1 ? nwin - 1 : w; };
-    std::vector<uint8_t> in2((size_t)nx * tpc, 0);
-    for (int x = 0; x < nx; x++) {
-        for (int t = 0; t < tpc; t++) {
-            const int r0 = t * 256, r1 = (r0 + 255 < ny - 1) ? r0 + 255 : ny - 1;
-            if (r0 > ny - 1) continue;                       // padding tile: nothing to compute
+    // zone = the outputs of the non-fusable units + columns 0,1,NX-2,NX-1; pass 2 covers it with
+    // window-aligned tiles (x, w), pass 1 additionally the columns left and right of it
+    std::vector<uint8_t> in2((size_t)nx * nwin, 0), in1((size_t)nx * nwin, 0);
+    for (int x = 0; x < nx; x++)
+        for (int w = 0; w < nwin; w++) {
             bool covered = (x >= ca && x < cb);
-            if (covered) {
-                const int q = (x - ca) / L;
-                for (int w = window_of_row(r0); w <= window_of_row(r1) && covered; w++) covered = fus[(size_t)q * nwin + w] != 0;
-            }
-            if (!covered) in2[(size_t)x * tpc + t] = 1;
+            if (covered) covered = fus[(size_t)((x - ca) / L) * nwin + w] != 0;
+            if (!covered) in2[(size_t)x * nwin + w] = 1;
         }
-    }
-    std::vector<uint8_t> in1((size_t)nx * tpc, 0);
     for (int x = 0; x < nx; x++)
-        for (int t = 0; t < tpc; t++) {
-            if (!in2[(size_t)x * tpc + t]) continue;
-            p.t2.push_back(x * tpc + t);
+        for (int w = 0; w < nwin; w++) {
+            if (!in2[(size_t)x * nwin + w]) continue;
+            p.t2.push_back(x * nwin + w);
             for (int dx = -1; dx <= 1; dx++)
-                for (int dt = -1; dt <= 1; dt++) {
-                    const int xx = x + dx, tt = t + dt;
-                    if (xx >= 0 && xx < nx && tt >= 0 && tt < tpc && tt * 256 <= ny - 1) in1[(size_t)xx * tpc + tt] = 1;
-                }
+                if (x + dx >= 0 && x + dx < nx) in1[(size_t)(x + dx) * nwin + w] = 1;
         }
     for (int x = 0; x < nx; x++)
-        for (int t = 0; t < tpc; t++)
-            if (in1[(size_t)x * tpc + t]) p.t1.push_back(x * tpc + t);
+        for (int w = 0; w < nwin; w++)
+            if (in1[(size_t)x * nwin + w]) p.t1.push_back(x * nwin + w);
+    p.nwin = nwin;
     p.usable = !p.units.empty();
     return p;
 }

@@ -91,12 +91,14 @@ struct wt_handle {
     wt_handle *peer_l = nullptr, *peer_r = nullptr;   // TR_LOCAL
     // two-steps-per-launch mode (step_fused.hpp); whole-lattice fp32 handles only
     bool fuse = false;
-    int fuse_chunk = 24;
+    int fuse_chunk = 0;                  // 0 = chosen per mask (auto_fuse_chunk)
     bool fuse_ready = false;
+    int fuse_chunk_used = 0;
     void *f_tmp = nullptr;               // third lattice for the non-fusable zone
     FuseUnit *d_units = nullptr;
     int *d_t1 = nullptr, *d_t2 = nullptr;
-    int n_units = 0, n_t1 = 0, n_t2 = 0;
+    int n_units = 0, n_t1 = 0, n_t2 = 0, n_win = 0;
+    uint8_t *wtiles = nullptr;           // classes of the window-aligned tiles (nxl x n_win)
     std::vector<uint8_t> host_mask;      // copy of the last mask (plan rebuilds when an option changes)
 };
 
@@ -207,7 +209,7 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
         const char *e = getenv("WT_FUSE2");
         h->fuse = e && atoi(e) != 0;
         const char *c = getenv("WT_FUSE_CHUNK");
-        if (c && atoi(c) > 0) h->fuse_chunk = atoi(c);
+        if (c && atoi(c) >= 0) h->fuse_chunk = atoi(c);
     }
     *out = h;
     return WT_OK;
@@ -242,6 +244,7 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->d_units) (void)hipFree(h->d_units);
     if (h->d_t1) (void)hipFree(h->d_t1);
     if (h->d_t2) (void)hipFree(h->d_t2);
+    if (h->wtiles) (void)hipFree(h->wtiles);
     if (h->partials) (void)hipFree(h->partials);
     if (h->partials_host) (void)hipHostFree(h->partials_host);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -297,12 +300,24 @@ static int rebuild_fuse_plan(wt_handle *h)
     h->fuse_ready = false;
     if (!h->fuse || !fuse_eligible(h) || h->host_mask.empty()) return WT_OK;
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    const FusePlan p = build_fuse_plan(h->host_mask.data(), h->g.nx_g, h->g.ny, h->tiles_per_col, h->fuse_chunk);
+    const FuseScan sc = scan_mask(h->host_mask.data(), h->g.nx_g, h->g.ny);
+    int L = h->fuse_chunk;
+    if (L <= 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+        L = auto_fuse_chunk(sc, (long)prop.multiProcessorCount * 8);     // 4 SIMDs x 2 resident fused waves
+    }
+    const FusePlan p = build_fuse_plan(sc, L);
+    h->fuse_chunk_used = L;
     if (!p.usable) return WT_OK;
     WT_TRY(upload_vec(&h->d_units, p.units, h));
     WT_TRY(upload_vec(&h->d_t1, p.t1, h));
     WT_TRY(upload_vec(&h->d_t2, p.t2, h));
-    h->n_units = (int)p.units.size(); h->n_t1 = (int)p.t1.size(); h->n_t2 = (int)p.t2.size();
+    h->n_units = (int)p.units.size(); h->n_t1 = (int)p.t1.size(); h->n_t2 = (int)p.t2.size(); h->n_win = p.nwin;
+    if (h->wtiles) { HIP_TRY(hipFree(h->wtiles)); h->wtiles = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->wtiles, (size_t)h->g.nxl * p.nwin));
+    WT_TRY(classify_tiles(h->mask, h->wtiles, h->g, p.nwin, h->s_compute, 256, FUSE_WIN_STRIDE));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
     if (!h->f_tmp) {
         const size_t lat_bytes = (size_t)9 * h->g.plane * h->esz;
         HIP_TRY(hipMalloc(&h->f_tmp, lat_bytes));
@@ -328,7 +343,7 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         return rebuild_fuse_plan(h);
     }
     if (strcmp(name, "fuse_chunk") == 0) {
-        if (!(value >= 1.0 && value <= 4096.0)) return fail(WT_ERR_ARG, "fuse_chunk out of range");
+        if (!(value >= 0.0 && value <= 4096.0)) return fail(WT_ERR_ARG, "fuse_chunk out of range (0 = automatic)");
         h->fuse_chunk = (int)value;
         return rebuild_fuse_plan(h);
     }
@@ -341,7 +356,7 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (!name || !value) return fail(WT_ERR_ARG, "null argument");
     if (strcmp(name, "fuse_steps") == 0) { *value = h->fuse ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fuse_active") == 0) { *value = h->fuse_ready ? 1.0 : 0.0; return WT_OK; }
-    if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_chunk; return WT_OK; }
+    if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_ready ? h->fuse_chunk_used : h->fuse_chunk; return WT_OK; }
     if (strcmp(name, "fuse_units") == 0) { *value = h->n_units; return WT_OK; }
     if (strcmp(name, "fuse_tiles_single") == 0) { *value = h->n_t2; return WT_OK; }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
@@ -578,15 +593,15 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
         HIP_TRY(hipEventRecord(h->ev_state, st));
         HIP_TRY(hipStreamWaitEvent(sz, h->ev_state, 0));
         if (h->n_t1)
-            hipLaunchKernelGGL((k_step_list<float, false, WT_LOADMODE>), dim3((h->n_t1 + 3) / 4), dim3(256), 0, sz, A, C, macro, h->mask,
-                               h->tiles, h->tiles_per_col, g, (const int *)h->d_t1, h->n_t1, t, U, rev);
+            hipLaunchKernelGGL((k_step_list<float, false, WT_LOADMODE, 1>), dim3((h->n_t1 + 3) / 4), dim3(256), 0, sz, A, C, macro, h->mask,
+                               h->wtiles, h->n_win, g, (const int *)h->d_t1, h->n_t1, t, U, rev);
         if (h->n_t2) {
             if (emit)
-                hipLaunchKernelGGL((k_step_list<float, true, WT_LOADMODE>), dim3((h->n_t2 + 3) / 4), dim3(256), 0, sz, (const float *)C, B,
-                                   macro, h->mask, h->tiles, h->tiles_per_col, g, (const int *)h->d_t2, h->n_t2, t, U, rev);
+                hipLaunchKernelGGL((k_step_list<float, true, WT_LOADMODE, 2>), dim3((h->n_t2 + 3) / 4), dim3(256), 0, sz, (const float *)C, B,
+                                   macro, h->mask, h->wtiles, h->n_win, g, (const int *)h->d_t2, h->n_t2, t, U, rev);
             else
-                hipLaunchKernelGGL((k_step_list<float, false, WT_LOADMODE>), dim3((h->n_t2 + 3) / 4), dim3(256), 0, sz, (const float *)C, B,
-                                   macro, h->mask, h->tiles, h->tiles_per_col, g, (const int *)h->d_t2, h->n_t2, t, U, rev);
+                hipLaunchKernelGGL((k_step_list<float, false, WT_LOADMODE, 2>), dim3((h->n_t2 + 3) / 4), dim3(256), 0, sz, (const float *)C, B,
+                                   macro, h->mask, h->wtiles, h->n_win, g, (const int *)h->d_t2, h->n_t2, t, U, rev);
         }
         HIP_TRY(hipEventRecord(h->ev_halo, sz));
     }

@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the NumPy CPU baseline (0 = skip)")
     ap.add_argument("--fuse", type=int, default=0, choices=[0, 1],
                     help="1: two steps per pass over the lattice (csrc/step_fused.hpp; single GPU, fp32; bit-identical)")
-    ap.add_argument("--fuse-chunk", type=int, default=24)
+    ap.add_argument("--fuse-chunk", type=int, default=0, help="columns per marching chunk (0 = chosen per mask)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -189,6 +189,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload, "nx": nx_total, "ny": ny, "slabs": world,
                    "halo": args.halo if distributed else 0, "fuse_steps": int(fused),
+                   "fuse_chunk": int(eng.get_option("fuse_chunk")) if fused else 0,
                    "solid_sites": int((mask != 0).sum())},
         "roofline": {
             "bound": "hbm",
