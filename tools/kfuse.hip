@@ -450,14 +450,8 @@ int main(int argc, char **argv)
     struct Var { std::string name; std::function<void(const float *, float *, int)> fn; std::vector<float> ms; int steps; };
     std::vector<Var> vs;
     vs.push_back({"production, 2 launches", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, f1, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(f1, b, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
-    vs.push_back({"fused L=8", [&](const float *a, float *b, int r) { launch2(k_step2<8>, 8, a, b, r); }, {}, 2});
-    vs.push_back({"fused L=16", [&](const float *a, float *b, int r) { launch2(k_step2<16>, 16, a, b, r); }, {}, 2});
-    vs.push_back({"fused L=32", [&](const float *a, float *b, int r) { launch2(k_step2<32>, 32, a, b, r); }, {}, 2});
-    vs.push_back({"fused+prefetch L=8", [&](const float *a, float *b, int r) { launch2(k_step2p<8>, 8, a, b, r); }, {}, 2});
-    vs.push_back({"fused+prefetch L=12", [&](const float *a, float *b, int r) { launch2(k_step2p<12>, 12, a, b, r); }, {}, 2});
     vs.push_back({"fused+prefetch L=16", [&](const float *a, float *b, int r) { launch2(k_step2p<16>, 16, a, b, r); }, {}, 2});
     vs.push_back({"fused+prefetch L=24", [&](const float *a, float *b, int r) { launch2(k_step2p<24>, 24, a, b, r); }, {}, 2});
-    vs.push_back({"fused+prefetch L=32", [&](const float *a, float *b, int r) { launch2(k_step2p<32>, 32, a, b, r); }, {}, 2});
     auto launchg = [&](auto kern, int NS, bool queue, int L, int wavesPerSimd, const float *a, float *b, int rev) {
         const int WS = 64 * NS - 4;
         const int nw = (ny - 2 + WS - 1) / WS;
@@ -467,11 +461,10 @@ int main(int argc, char **argv)
         if (queue) { CK(hipMemsetAsync(counter, 0, 4, st)); blocks = 256L * wavesPerSimd; if (blocks * 4 > nunits) blocks = (nunits + 3) / 4; }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, a, b, g, ca, cb, L, nw, tau, U0, rev, counter);
     };
-    for (int L : {8, 12, 16, 24}) {
-        vs.push_back({"g NS=4 static L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1>, 4, false, L, 2, a, b, r); }, {}, 2});
-        vs.push_back({"g NS=4 queue  L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, true, 1>, 4, true, L, 2, a, b, r); }, {}, 2});
-        vs.push_back({"g NS=2 static L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<2, false, 1>, 2, false, L, 4, a, b, r); }, {}, 2});
-        vs.push_back({"g NS=2 queue  L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<2, true, 1>, 2, true, L, 4, a, b, r); }, {}, 2});
+    for (int L : {12, 16, 24, 32}) {
+        vs.push_back({"g NS=4 static minw1 L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1>, 4, false, L, 2, a, b, r); }, {}, 2});
+        vs.push_back({"g NS=4 static minw3 L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 3>, 4, false, L, 2, a, b, r); }, {}, 2});
+        vs.push_back({"g NS=2 static minw4 L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<2, false, 4>, 2, false, L, 4, a, b, r); }, {}, 2});
     }
     const int reps = 4;
     for (int r = 0; r < rounds + 2; r++)
