@@ -130,3 +130,79 @@ class SlabWindTunnel(WindTunnel):
 
     def frame(self, render: bool = False):
         return super().frame(render=render)
+
+
+class _LocalSlabEngine:
+    """Engine-shaped facade over P locally linked slab handles (one process, any mix of devices):
+    ghost columns move by peer copies (wt_link_local), all slabs advance in lock-step (wt_step_group)."""
+
+    def __init__(self, nx, ny, dtype, devices, halo):
+        from ._capi import Engine
+        self._Engine = Engine
+        P = len(devices)
+        self.slabs = [Engine(nx, ny, dtype=dtype, device=d, rank=r, nranks=P, halo=halo) for r, d in enumerate(devices)]
+        Engine.link_local(self.slabs)
+        self.dtype = self.slabs[0].dtype
+        self.nx_global, self.ny, self.x0, self.width = nx, ny, 0, nx
+
+    def close(self):
+        for s in self.slabs:
+            s.close()
+
+    def set_mask(self, mask):
+        for s in self.slabs:
+            s.set_mask(mask)
+
+    def init_equilibrium(self, u0):
+        for s in self.slabs:
+            s.init_equilibrium(u0)
+
+    def step(self, nsteps, tau, u0):
+        self._Engine.step_group(self.slabs, nsteps, tau, u0)
+
+    def read_f(self):
+        return np.concatenate([s.read_f() for s in self.slabs], axis=2)
+
+    def write_f(self, f):
+        for s in self.slabs:
+            s.write_f(np.ascontiguousarray(f[:, :, s.x0:s.x0 + s.width]))
+
+    def read_macro(self):
+        parts = [s.read_macro() for s in self.slabs]
+        return tuple(np.concatenate([p[a] for p in parts], axis=1) for a in range(3))
+
+    def reduce_ranges(self, u0):
+        rr = [s.reduce_ranges(u0) for s in self.slabs]
+        return max(r[0] for r in rr), min(r[1] for r in rr), max(r[2] for r in rr)
+
+    def forces(self):
+        ff = [s.forces() for s in self.slabs]
+        return tuple(sum(x[a] for x in ff) for a in range(4))
+
+    def field(self, *args):
+        return np.concatenate([s.field(*args) for s in self.slabs], axis=1)
+
+    def render_rgba(self, *args):
+        return np.concatenate([s.render_rgba(*args) for s in self.slabs], axis=1)
+
+    def advect_tracers(self, *args):
+        raise NotImplementedError("tracers need the whole lattice on one handle")
+
+    def sync(self):
+        for s in self.slabs:
+            s.sync()
+
+
+class LocalSlabWindTunnel(WindTunnel):
+    """:class:`WindTunnel` over several GPUs driven by ONE process (no torch.distributed, no RCCL):
+    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=16, nx=8192, ny=4096)``."""
+
+    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: int = 16, **kwargs):
+        self.devices = [int(d) for d in devices]
+        self.halo = int(halo)
+        if len(self.devices) < 2:
+            raise ValueError("LocalSlabWindTunnel needs at least two slabs; use WindTunnel for one GPU")
+        super().__init__(coords, name, device=self.devices[0], **kwargs)
+
+    def _make_engine(self, dtype, device):
+        return _LocalSlabEngine(self.nx, self.ny, dtype, self.devices, self.halo)

@@ -144,3 +144,20 @@ def test_slab_wind_tunnel_with_real_engine_world1(pkg, oracle_c):
             assert t.shape == (256, 512) and wt.stats().cl is not None
     finally:
         dist.destroy_process_group()
+
+
+def test_local_slab_wind_tunnel_one_process(pkg, oracle_c):
+    """One process driving several slab handles (here all on GPU 0): the WindTunnel surface, unchanged."""
+    from airfoil_cfd_tool_amd.distributed import LocalSlabWindTunnel
+    with LocalSlabWindTunnel(shape="naca4412", nx=768, ny=256, aoa_deg=9.0, devices=[0, 0, 0], halo=5) as wt, \
+            pkg.WindTunnel(shape="naca4412", nx=768, ny=256, aoa_deg=9.0) as ref:
+        for _ in range(7):
+            wt.frame(); ref.frame()
+        wt.aoa_deg = 13.0; ref.aoa_deg = 13.0
+        wt.sim_step(9); ref.sim_step(9)
+        assert bits_equal(wt.read_f(), ref.read_f())
+        assert all(bits_equal(a, b) for a, b in zip(wt.read_macro(), ref.read_macro()))
+        assert wt.update_fields_from_macro() == ref.update_fields_from_macro()
+        np.testing.assert_allclose([wt.cl_smooth, wt.cd_smooth, wt.sep_frac], [ref.cl_smooth, ref.cd_smooth, ref.sep_frac], rtol=1e-12)
+        assert np.array_equal(wt.render_rgba("vort"), ref.render_rgba("vort"))
+        assert wt.stats().separation == ref.stats().separation
