@@ -500,6 +500,8 @@ static int exchange_rccl(wt_handle *h)
 static int exchange_local(wt_handle *h)
 {
     const size_t bytes = (size_t)h->halo * h->g.pitch * h->esz;
+    if ((h->gl && !h->peer_l) || (h->gr && !h->peer_r))
+        return fail(WT_ERR_STATE, "a neighbouring slab of this locally linked group has been destroyed");
     for (int k = 0; k < 9; k++) {
         if (h->gl) {
             wt_handle *p = h->peer_l;
