@@ -282,7 +282,8 @@ extern "C" int wt_sync(wt_handle *h)
 // ------------------------------------------------------------------------------------------
 // two-steps-per-launch plan
 // ------------------------------------------------------------------------------------------
-static bool fuse_eligible(const wt_handle *h) { return h->nranks == 1 && h->dtype == WT_F32 && h->g.ny % 4 == 0; }
+// whole lattices and column slabs alike (a slab plans over its LOCAL columns, ghosts included)
+static bool fuse_eligible(const wt_handle *h) { return h->dtype == WT_F32 && h->g.ny % 4 == 0 && h->g.nxl >= 8; }
 
 template <typename U>
 static int upload_vec(U **dptr, const std::vector<U> &v, wt_handle *h)
@@ -300,7 +301,7 @@ static int rebuild_fuse_plan(wt_handle *h)
     h->fuse_ready = false;
     if (!h->fuse || !fuse_eligible(h) || h->host_mask.empty()) return WT_OK;
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    const FuseScan sc = scan_mask(h->host_mask.data(), h->g.nx_g, h->g.ny);
+    const FuseScan sc = scan_mask(h->host_mask.data(), h->g.nxl, h->g.ny);      // host_mask: [NY][nxl], local columns
     int L = h->fuse_chunk;
     if (L <= 0) {
         hipDeviceProp_t prop;
@@ -338,7 +339,7 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
     HIP_TRY(hipSetDevice(h->device));
     if (strcmp(name, "fuse_steps") == 0) {
         if (value != 0.0 && !fuse_eligible(h))
-            return fail(WT_ERR_STATE, "fuse_steps needs a whole-lattice fp32 handle with NY %% 4 == 0");
+            return fail(WT_ERR_STATE, "fuse_steps needs an fp32 handle with NY %% 4 == 0 and at least 8 local columns");
         h->fuse = value != 0.0;
         return rebuild_fuse_plan(h);
     }
@@ -407,7 +408,10 @@ extern "C" int wt_set_mask(wt_handle *h, const uint8_t *mask)
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     h->mask_set = true;
     if (fuse_eligible(h)) {
-        h->host_mask.assign(mask, mask + (size_t)g.nx_g * g.ny);
+        // keep the LOCAL columns [gi0, gi0+nxl) of the mask (all inside the tunnel) for the fusion plan
+        h->host_mask.resize((size_t)g.nxl * g.ny);
+        for (int y = 0; y < g.ny; y++)
+            memcpy(h->host_mask.data() + (size_t)y * g.nxl, mask + (size_t)y * g.nx_g + g.gi0, (size_t)g.nxl);
         WT_TRY(rebuild_fuse_plan(h));
     }
     return WT_OK;
@@ -617,18 +621,25 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     HIP_TRY(hipGetLastError());
     h->cur = 1 - h->cur;
     h->steps_done += 2;
+    if (h->nranks > 1) h->ghost_valid -= 2;      // two columns of ghost validity consumed
     return WT_OK;
 }
+
+// a fused pair is possible now: plan ready and (slabs) two exact ghost columns left
+static inline bool can_pair(const wt_handle *h) { return h->fuse_ready && (h->nranks == 1 || h->ghost_valid >= 2); }
 
 static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
 {
     int s = 0;
-    if (h->fuse_ready && h->nranks == 1 && nsteps >= 2) {
-        if (nsteps & 1) { WT_TRY(step_once(h, tau, u0, false)); s = 1; }
-        for (; s < nsteps; s += 2) WT_TRY(step_pair_fused(h, tau, u0, s + 2 == nsteps));
-        return WT_OK;
+    while (s < nsteps) {
+        if (nsteps - s >= 2 && can_pair(h)) {
+            WT_TRY(step_pair_fused(h, tau, u0, s + 2 == nsteps));
+            s += 2;
+        } else {
+            WT_TRY(step_once(h, tau, u0, s + 1 == nsteps));
+            s += 1;
+        }
     }
-    for (; s < nsteps; s++) WT_TRY(step_once(h, tau, u0, s == nsteps - 1));
     return WT_OK;
 }
 
@@ -724,7 +735,18 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
         if (hs[r]->ghost_valid != hs[0]->ghost_valid || hs[r]->steps_done != hs[0]->steps_done)
             return fail(WT_ERR_STATE, "slabs are not at the same step");
     }
-    for (int s = 0; s < nsteps; s++) {
+    int s = 0;
+    while (s < nsteps) {
+        bool pair = nsteps - s >= 2;
+        for (int r = 0; r < n && pair; r++) pair = can_pair(hs[r]);
+        if (pair) {                                   // two steps per pass on every slab; no exchange involved
+            for (int r = 0; r < n; r++) {
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                WT_TRY(step_pair_fused(hs[r], tau, u0, s + 2 == nsteps));
+            }
+            s += 2;
+            continue;
+        }
         const bool emit = (s == nsteps - 1);
         const bool refresh = n > 1 && hs[0]->ghost_valid == 0;
         if (refresh) {
@@ -757,6 +779,7 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
                 if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_r->ev_halo, 0));
             }
         }
+        s += 1;
     }
     return WT_OK;
 }

@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--halo", type=int, default=16, help="ghost columns per interior slab side (exchange every `halo` steps)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the NumPy CPU baseline (0 = skip)")
     ap.add_argument("--fuse", type=int, default=0, choices=[0, 1],
-                    help="1: two steps per pass over the lattice (csrc/step_fused.hpp; single GPU, fp32; bit-identical)")
+                    help="1: two steps per pass over the lattice (csrc/step_fused.hpp; fp32; bit-identical)")
     ap.add_argument("--fuse-chunk", type=int, default=0, help="columns per marching chunk (0 = chosen per mask)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
@@ -128,6 +128,9 @@ def main():
 
     if distributed:
         eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank, rank=rank, nranks=world, halo=args.halo)
+        if args.fuse:
+            eng.set_option("fuse_chunk", args.fuse_chunk)
+            eng.set_option("fuse_steps", 1)
         ids = [wtpkg.Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         eng.comm_init_rank(ids[0])
@@ -166,7 +169,7 @@ def main():
     sites = nx_total * ny
     mlups = sites * args.steps / wall / 1e6
     bpl = BYTES_PER_LUP[args.dtype]
-    fused = bool(not distributed and args.fuse and eng.get_option("fuse_active"))
+    fused = bool(args.fuse and eng.get_option("fuse_active"))
     launch_ms = dev_ms / args.steps                      # one step = one launch of k_step over the slab
     if fused:
         launch_ms *= 2.0                                 # one pass (k_step2 + the two list passes) = TWO steps

@@ -133,3 +133,34 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
         assert np.isfinite(rho).all() and np.isfinite(ux).all() and np.isfinite(uy).all()
         assert float(rho.min()) >= 0.5 and float(rho.max()) <= 2.0
         assert float(np.hypot(ux, uy).max()) <= 0.35 * (1 + 1e-6)          # html:344-350 clamp bounds
+
+
+@pytest.mark.parametrize("nranks,halo,nx,ny,chunks", [
+    (2, 4, 512, 256, [1, 2, 3, 8, 21]),
+    (3, 7, 768, 512, [40]),
+    (4, 16, 2048, 512, [33, 18]),
+    (2, 1, 512, 256, [9]),              # halo 1: never two exact ghost columns -> single steps only
+    (8, 16, 4096, 256, [50]),
+])
+def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks):
+    """Two-steps-per-launch on column slabs (in-process transport): a pair needs two exact ghost
+    columns, refresh steps stay single; results equal the plain single lattice bit for bit."""
+    mask = _body(pkg, nx, ny, "naca2412", 7.0)
+    f0, m0, _ = _run(pkg, mask, chunks, 0.58, 0.06, False)
+    es = [pkg.Engine(nx, ny, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_option("fuse_steps", 1)
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        assert any(e.get_option("fuse_active") == 1.0 for e in es)
+        for n in chunks:
+            pkg.Engine.step_group(es, n, 0.58, 0.06)
+        f1 = np.concatenate([e.read_f() for e in es], axis=2)
+        m1 = [np.concatenate(p, axis=1) for p in zip(*[e.read_macro() for e in es])]
+        assert all(e.info().steps_done == sum(chunks) for e in es)
+    finally:
+        for e in es:
+            e.close()
+    assert bits_equal(f0, f1)
+    assert all(bits_equal(a, b) for a, b in zip(m0, m1))
