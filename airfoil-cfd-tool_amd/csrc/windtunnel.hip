@@ -91,6 +91,7 @@ struct wt_handle {
     wt_handle *peer_l = nullptr, *peer_r = nullptr;   // TR_LOCAL
     // two-steps-per-launch mode (step_fused.hpp); whole-lattice fp32 handles only
     bool fuse = false;
+    bool fuse_force = false;             // fuse_steps = 2: also when the lattice is too small for it to pay
     int fuse_chunk = 0;                  // 0 = chosen per mask (auto_fuse_chunk)
     bool fuse_ready = false;
     int fuse_chunk_used = 0;
@@ -208,6 +209,7 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     {
         const char *e = getenv("WT_FUSE2");
         h->fuse = e && atoi(e) != 0;
+        h->fuse_force = e && atoi(e) >= 2;
         const char *c = getenv("WT_FUSE_CHUNK");
         if (c && atoi(c) >= 0) h->fuse_chunk = atoi(c);
     }
@@ -302,15 +304,17 @@ static int rebuild_fuse_plan(wt_handle *h)
     if (!h->fuse || !fuse_eligible(h) || h->host_mask.empty()) return WT_OK;
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     const FuseScan sc = scan_mask(h->host_mask.data(), h->g.nxl, h->g.ny);      // host_mask: [NY][nxl], local columns
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    const long capacity = (long)prop.multiProcessorCount * 8;            // 4 SIMDs x 2 resident fused waves
     int L = h->fuse_chunk;
-    if (L <= 0) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-        L = auto_fuse_chunk(sc, (long)prop.multiProcessorCount * 8);     // 4 SIMDs x 2 resident fused waves
-    }
+    if (L <= 0) L = auto_fuse_chunk(sc, capacity);
     const FusePlan p = build_fuse_plan(sc, L);
     h->fuse_chunk_used = L;
     if (!p.usable) return WT_OK;
+    // measured (bench.py --fuse on 544/1056/2080-column lattices): with fewer units than resident
+    // wave slots the marching kernel cannot fill the chip and the single-step kernel is faster
+    if (!h->fuse_force && (long)p.units.size() < capacity) return WT_OK;
     WT_TRY(upload_vec(&h->d_units, p.units, h));
     WT_TRY(upload_vec(&h->d_t1, p.t1, h));
     WT_TRY(upload_vec(&h->d_t2, p.t2, h));
@@ -341,6 +345,7 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         if (value != 0.0 && !fuse_eligible(h))
             return fail(WT_ERR_STATE, "fuse_steps needs an fp32 handle with NY %% 4 == 0 and at least 8 local columns");
         h->fuse = value != 0.0;
+        h->fuse_force = value >= 2.0;
         return rebuild_fuse_plan(h);
     }
     if (strcmp(name, "fuse_chunk") == 0) {

@@ -16,7 +16,7 @@ def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None):
         if fuse:
             if chunk is not None:
                 e.set_option("fuse_chunk", chunk)
-            e.set_option("fuse_steps", 1)
+            e.set_option("fuse_steps", 2)
         e.set_mask(mask)
         e.init_equilibrium(u0)
         if fuse:
@@ -66,7 +66,7 @@ def test_fused_low_tau_clamp_and_mask_change(pkg, oracle_c):
     nx, ny = 512, 256
     m1, m2 = _body(pkg, nx, ny, "naca4412", 20.0), _body(pkg, nx, ny, "naca4412", 5.0)
     with pkg.Engine(nx, ny) as e:
-        e.set_option("fuse_steps", 1)
+        e.set_option("fuse_steps", 2)
         e.set_mask(m1); e.init_equilibrium(0.10); e.step(300, 0.5004, 0.10)
         e.set_mask(m2); e.step(100, 0.5004, 0.09)
         f, m = e.read_f(), e.read_macro()
@@ -83,7 +83,7 @@ def test_fused_toggle_midrun_and_4096(pkg):
             e.set_mask(mask); e.init_equilibrium(0.06)
         a.step(9, 0.58, 0.06)
         b.step(3, 0.58, 0.06)
-        b.set_option("fuse_steps", 1)            # option set after the mask: the plan is rebuilt from the kept copy
+        b.set_option("fuse_steps", 2)            # option set after the mask: the plan is rebuilt from the kept copy
         assert b.get_option("fuse_active") == 1.0
         b.step(4, 0.58, 0.06)
         b.set_option("fuse_steps", 0)
@@ -97,14 +97,14 @@ def test_fused_toggle_midrun_and_4096(pkg):
 def test_fused_not_available(pkg):
     with pkg.Engine(256, 128, dtype="float64") as e:
         with pytest.raises(pkg.WTError):
-            e.set_option("fuse_steps", 1)
+            e.set_option("fuse_steps", 2)
     with pkg.Engine(256, 130) as e:
         with pytest.raises(pkg.WTError):
-            e.set_option("fuse_steps", 1)
+            e.set_option("fuse_steps", 2)
         with pytest.raises(pkg.WTError):
             e.set_option("no_such_option", 1)
     with pkg.Engine(64, 64) as e:               # eligible but tiny: a plan with few units still works
-        e.set_option("fuse_steps", 1)
+        e.set_option("fuse_steps", 2)
         e.set_mask(np.zeros((64, 64), np.uint8)); e.init_equilibrium(0.06); e.step(6, 0.58, 0.06)
         assert e.info().steps_done == 6
 
@@ -118,7 +118,7 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
     digests = []
     for fuse in (0, 1):
         with pkg.Engine(nx, ny) as e:
-            e.set_option("fuse_steps", fuse)
+            e.set_option("fuse_steps", 2 * fuse)
             e.set_mask(mask); e.init_equilibrium(0.06)
             for _ in range(5):
                 e.step(1000, 0.58, 0.06)
@@ -127,7 +127,7 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
             digests.append(hashlib.sha256(rho.tobytes() + ux.tobytes() + uy.tobytes()).hexdigest())
     assert digests[0] == digests[1]
     with pkg.WindTunnel(shape="naca4412", nx=2048, ny=1024, aoa_deg=12.0, re=1e6 * 2048 / 4096) as wt:
-        wt.engine.set_option("fuse_steps", 1)
+        wt.engine.set_option("fuse_steps", 2)
         wt.sim_step(3000)
         rho, ux, uy = wt.read_macro()
         assert np.isfinite(rho).all() and np.isfinite(ux).all() and np.isfinite(uy).all()
@@ -151,7 +151,7 @@ def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks):
     try:
         pkg.Engine.link_local(es)
         for e in es:
-            e.set_option("fuse_steps", 1)
+            e.set_option("fuse_steps", 2)
             e.set_mask(mask); e.init_equilibrium(0.06)
         assert any(e.get_option("fuse_active") == 1.0 for e in es)
         for n in chunks:
@@ -164,3 +164,15 @@ def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks):
             e.close()
     assert bits_equal(f0, f1)
     assert all(bits_equal(a, b) for a, b in zip(m0, m1))
+
+
+def test_fuse_auto_only_where_it_pays(pkg):
+    """fuse_steps = 1 engages only when the plan has at least as many units as resident wave slots."""
+    with pkg.Engine(512, 256) as small, pkg.Engine(4096, 1024) as big:
+        for e in (small, big):
+            e.set_option("fuse_steps", 1)
+            e.set_mask(np.zeros((e.ny, e.nx_global), np.uint8)); e.init_equilibrium(0.06)
+        assert small.get_option("fuse_active") == 0.0 and big.get_option("fuse_active") == 1.0
+        small.set_option("fuse_steps", 2)
+        assert small.get_option("fuse_active") == 1.0
+        small.step(6, 0.58, 0.06); big.step(6, 0.58, 0.06)

@@ -44,7 +44,7 @@ def test_random_case(pkg, oracle_c, seed):
                 if dtype != "float32" or ny % 4:
                     continue
                 e.set_option("fuse_chunk", int(rng.integers(1, 40)))
-                e.set_option("fuse_steps", 1)
+                e.set_option("fuse_steps", 2)
             e.set_mask(mask); e.init_equilibrium(u0)
             for n in steps:
                 e.step(n, tau, u0)
