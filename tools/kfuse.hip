@@ -261,6 +261,21 @@ template <int NS> __device__ __forceinline__ void load9(const float *__restrict_
     fin[7] = ldv<NS>(s + 7 * P + c + g.pitch + 1, true);
     fin[8] = ldv<NS>(s + 8 * P + c - g.pitch + 1, true);
 }
+// aligned 16-B loads only; the +-1 shifts come from the neighbouring lanes (window-edge rows become
+// invalid one step earlier, which costs nothing: those rows are not stored anyway)
+template <int NS> __device__ __forceinline__ void load9a(const float *__restrict__ s, const Geom &g, long P, int col, int j0, VecN<NS> (&fin)[9])
+{
+    const long c = (long)col * g.pitch + j0;
+    fin[0] = ldv<NS>(s + 0 * P + c, false);
+    fin[1] = ldv<NS>(s + 1 * P + c - g.pitch, false);
+    fin[3] = ldv<NS>(s + 3 * P + c + g.pitch, false);
+    fin[2] = ldv<NS>(s + 2 * P + c, false);
+    fin[5] = ldv<NS>(s + 5 * P + c - g.pitch, false);
+    fin[6] = ldv<NS>(s + 6 * P + c + g.pitch, false);
+    fin[4] = ldv<NS>(s + 4 * P + c, false);
+    fin[7] = ldv<NS>(s + 7 * P + c + g.pitch, false);
+    fin[8] = ldv<NS>(s + 8 * P + c - g.pitch, false);
+}
 template <int NS> __device__ __forceinline__ void collideN(const VecN<NS> (&fin)[9], const Geom &g, int j0, float tau, const float (&feq0)[9], VecN<NS> (&G)[9])
 {
 #pragma unroll
@@ -292,7 +307,7 @@ template <int NS> __device__ __forceinline__ VecN<NS> aboveN(const VecN<NS> &r)
 }
 
 // QUEUE: units are taken from a global atomic counter by persistent waves (grid = resident capacity)
-template <int NS, bool QUEUE, int MINW>
+template <int NS, bool QUEUE, int MINW, bool ALIGNED = false>
 __global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ fs, float *__restrict__ fd, Geom g, int ca, int cb, int L, int nwin,
                                                       float tau, float U0, int rev, unsigned int *__restrict__ counter)
 {
@@ -305,6 +320,9 @@ __global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ 
     const long P = g.plane;
     float feq0[9];
     feq_all<float>(1.0f, U0, 0.0f, feq0);
+#define FIXUP(v) do { v[2] = belowN<NS>(v[2]); v[5] = belowN<NS>(v[5]); v[6] = belowN<NS>(v[6]); v[4] = aboveN<NS>(v[4]); v[7] = aboveN<NS>(v[7]); v[8] = aboveN<NS>(v[8]); } while (0)
+#define LOADRAW(col, v) do { if (ALIGNED) load9a<NS>(s, g, P, (col), j0, v); else load9<NS>(s, g, P, (col), j0, v); } while (0)
+#define LOADIN(col, v) do { LOADRAW(col, v); } while (0)
     long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     for (;;) {
         if (QUEUE) {
@@ -319,18 +337,21 @@ __global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ 
         const int j0 = w * WS + lane * NS;
         const bool first_win = (w == 0);
         VecN<NS> G158m[3], G024c[3], G158c[3], in[9], G[9];
-        load9<NS>(s, g, P, ia - 1, j0, in);
+        LOADIN(ia - 1, in);
+        if (ALIGNED) { FIXUP(in); }
         collideN<NS>(in, g, j0, tau, feq0, G);
         G158m[0] = G[1]; G158m[1] = G[5]; G158m[2] = G[8];
-        load9<NS>(s, g, P, ia, j0, in);
+        LOADIN(ia, in);
+        if (ALIGNED) { FIXUP(in); }
         collideN<NS>(in, g, j0, tau, feq0, G);
         G024c[0] = G[0]; G024c[1] = G[2]; G024c[2] = G[4];
         G158c[0] = G[1]; G158c[1] = G[5]; G158c[2] = G[8];
-        load9<NS>(s, g, P, ia + 1, j0, in);
+        LOADIN(ia + 1, in);
 #pragma unroll 1
         for (int c = ia; c < ib; c++) {
             VecN<NS> nxt[9];
-            load9<NS>(s, g, P, (c + 2 <= ib) ? c + 2 : c + 1, j0, nxt);
+            LOADRAW((c + 2 <= ib) ? c + 2 : c + 1, nxt);
+            if (ALIGNED) { FIXUP(in); }
             collideN<NS>(in, g, j0, tau, feq0, G);
             VecN<NS> fin[9], out[9];
             fin[0] = G024c[0]; fin[1] = G158m[0]; fin[3] = G[3];
@@ -442,9 +463,9 @@ int main(int argc, char **argv)
             const long nunits = (long)((cb - ca + L - 1) / L) * nw;
             CK(hipMemsetAsync(counter, 0, 4, st));
             if (variant == 0) hipLaunchKernelGGL((k_step2g<2, true, 1>), dim3(1024), dim3(256), 0, st, f0, f3, g, ca, cb, L, nw, tau, U0, 0, counter);
-            else hipLaunchKernelGGL((k_step2g<4, false, 1>), dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, f0, f3, g, ca, cb, L, nw, tau, U0, 1, counter);
+            else hipLaunchKernelGGL((k_step2g<4, false, 1, true>), dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, f0, f3, g, ca, cb, L, nw, tau, U0, 1, counter);
             CK(hipStreamSynchronize(st)); CK(hipGetLastError());
-            check(variant == 0 ? "NS=2 queue L=12" : "NS=4 static L=12 rev");
+            check(variant == 0 ? "NS=2 queue L=12" : "NS=4 ALIGNED L=12 rev");
         }
     }
     struct Var { std::string name; std::function<void(const float *, float *, int)> fn; std::vector<float> ms; int steps; };
@@ -461,10 +482,9 @@ int main(int argc, char **argv)
         if (queue) { CK(hipMemsetAsync(counter, 0, 4, st)); blocks = 256L * wavesPerSimd; if (blocks * 4 > nunits) blocks = (nunits + 3) / 4; }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, a, b, g, ca, cb, L, nw, tau, U0, rev, counter);
     };
-    for (int L : {12, 16, 24, 32}) {
-        vs.push_back({"g NS=4 static minw1 L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1>, 4, false, L, 2, a, b, r); }, {}, 2});
-        vs.push_back({"g NS=4 static minw3 L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 3>, 4, false, L, 2, a, b, r); }, {}, 2});
-        vs.push_back({"g NS=2 static minw4 L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<2, false, 4>, 2, false, L, 4, a, b, r); }, {}, 2});
+    for (int L : {24, 35, 69}) {
+        vs.push_back({"unaligned L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1, false>, 4, false, L, 2, a, b, r); }, {}, 2});
+        vs.push_back({"aligned+shuffle L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1, true>, 4, false, L, 2, a, b, r); }, {}, 2});
     }
     const int reps = 4;
     for (int r = 0; r < rounds + 2; r++)
