@@ -307,7 +307,7 @@ template <int NS> __device__ __forceinline__ VecN<NS> aboveN(const VecN<NS> &r)
 }
 
 // QUEUE: units are taken from a global atomic counter by persistent waves (grid = resident capacity)
-template <int NS, bool QUEUE, int MINW, bool ALIGNED = false>
+template <int NS, bool QUEUE, int MINW, bool ALIGNED = false, int ORDER = 0>
 __global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ fs, float *__restrict__ fd, Geom g, int ca, int cb, int L, int nwin,
                                                       float tau, float U0, int rev, unsigned int *__restrict__ counter)
 {
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ 
             unit = __builtin_amdgcn_readfirstlane(u);
         }
         if (unit >= nunits) return;
-        const long uu = rev ? nunits - 1 - unit : unit;
+        const int xflags = rev >> 1;
+        const long uu = (rev & 1) ? nunits - 1 - unit : unit;
         const int q = (int)(uu / nwin), w = (int)(uu % nwin);
         const int ia = ca + q * L, ib = min(ia + L, cb);
         const int j0 = w * WS + lane * NS;
@@ -350,16 +351,17 @@ __global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ 
 #pragma unroll 1
         for (int c = ia; c < ib; c++) {
             VecN<NS> nxt[9];
-            LOADRAW((c + 2 <= ib) ? c + 2 : c + 1, nxt);
+            if (ORDER == 0 || ORDER == 2) { if (!(xflags & 2)) LOADRAW((c + 2 <= ib) ? c + 2 : c + 1, nxt); else { for (int k = 0; k < 9; k++) nxt[k] = in[k]; } }
             if (ALIGNED) { FIXUP(in); }
             collideN<NS>(in, g, j0, tau, feq0, G);
+            if (ORDER == 1) { __builtin_amdgcn_sched_barrier(0); LOADRAW((c + 2 <= ib) ? c + 2 : c + 1, nxt); __builtin_amdgcn_sched_barrier(0); }
             VecN<NS> fin[9], out[9];
             fin[0] = G024c[0]; fin[1] = G158m[0]; fin[3] = G[3];
             fin[2] = belowN<NS>(G024c[1]); fin[5] = belowN<NS>(G158m[1]); fin[6] = belowN<NS>(G[6]);
             fin[4] = aboveN<NS>(G024c[2]); fin[8] = aboveN<NS>(G158m[2]); fin[7] = aboveN<NS>(G[7]);
             collideN<NS>(fin, g, j0, tau, feq0, out);
             const long cc = (long)c * g.pitch + j0;
-            if (j0 + NS - 1 < g.ny) {
+            if (j0 + NS - 1 < g.ny && !(xflags & 1)) {
                 if (NS == 4) {
                     if (lane == 0 && !first_win) {
 #pragma unroll
@@ -382,8 +384,17 @@ __global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ 
             for (int k = 0; k < 3; k++) G158m[k] = G158c[k];
             G024c[0] = G[0]; G024c[1] = G[2]; G024c[2] = G[4];
             G158c[0] = G[1]; G158c[1] = G[5]; G158c[2] = G[8];
+            if (ORDER == 2) {
+                // materialise the copies HERE: the compiler then waits for the prefetched loads with a COUNTED
+                // vmcnt (the 9 stores issued after them stay in flight) instead of vmcnt(0) at the loop top
 #pragma unroll
-            for (int k = 0; k < 9; k++) in[k] = nxt[k];
+                for (int k = 0; k < 9; k++)
+#pragma unroll
+                    for (int v = 0; v < NS; v++) asm volatile("v_mov_b32 %0, %1" : "=v"(in[k].v[v]) : "v"(nxt[k].v[v]));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; k++) in[k] = nxt[k];
+            }
         }
         if (!QUEUE) return;
     }
@@ -463,9 +474,9 @@ int main(int argc, char **argv)
             const long nunits = (long)((cb - ca + L - 1) / L) * nw;
             CK(hipMemsetAsync(counter, 0, 4, st));
             if (variant == 0) hipLaunchKernelGGL((k_step2g<2, true, 1>), dim3(1024), dim3(256), 0, st, f0, f3, g, ca, cb, L, nw, tau, U0, 0, counter);
-            else hipLaunchKernelGGL((k_step2g<4, false, 1, true>), dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, f0, f3, g, ca, cb, L, nw, tau, U0, 1, counter);
+            else hipLaunchKernelGGL((k_step2g<4, false, 1, false, 2>), dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, f0, f3, g, ca, cb, L, nw, tau, U0, 1, counter);
             CK(hipStreamSynchronize(st)); CK(hipGetLastError());
-            check(variant == 0 ? "NS=2 queue L=12" : "NS=4 ALIGNED L=12 rev");
+            check(variant == 0 ? "NS=2 queue L=12" : "NS=4 counted-wait L=12 rev");
         }
     }
     struct Var { std::string name; std::function<void(const float *, float *, int)> fn; std::vector<float> ms; int steps; };
@@ -482,9 +493,9 @@ int main(int argc, char **argv)
         if (queue) { CK(hipMemsetAsync(counter, 0, 4, st)); blocks = 256L * wavesPerSimd; if (blocks * 4 > nunits) blocks = (nunits + 3) / 4; }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, a, b, g, ca, cb, L, nw, tau, U0, rev, counter);
     };
-    for (int L : {24, 35, 69}) {
-        vs.push_back({"unaligned L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1, false>, 4, false, L, 2, a, b, r); }, {}, 2});
-        vs.push_back({"aligned+shuffle L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1, true>, 4, false, L, 2, a, b, r); }, {}, 2});
+    for (int L : {12, 24, 35}) {
+        vs.push_back({"baseline L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1, false, 0>, 4, false, L, 2, a, b, r); }, {}, 2});
+        vs.push_back({"counted-wait copies L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1, false, 2>, 4, false, L, 2, a, b, r); }, {}, 2});
     }
     const int reps = 4;
     for (int r = 0; r < rounds + 2; r++)
