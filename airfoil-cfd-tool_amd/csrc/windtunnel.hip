@@ -207,9 +207,12 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     CREATE_TRY(hipStreamSynchronize(h->s_compute));
 #undef CREATE_TRY
     {
+        // Two steps per pass (step_fused.hpp): on by default for whole-lattice handles, where it engages
+        // only if the plan has enough units to pay (fuse_steps = 1); slab handles keep the plain path unless
+        // asked.  WT_FUSE2 = 0 | 1 | 2 overrides (off / where it pays / always).
+        h->fuse = (nranks == 1);
         const char *e = getenv("WT_FUSE2");
-        h->fuse = e && atoi(e) != 0;
-        h->fuse_force = e && atoi(e) >= 2;
+        if (e) { h->fuse = atoi(e) != 0; h->fuse_force = atoi(e) >= 2; }
         const char *c = getenv("WT_FUSE_CHUNK");
         if (c && atoi(c) >= 0) h->fuse_chunk = atoi(c);
     }

@@ -51,8 +51,9 @@ def parse_args():
     ap.add_argument("--tau", type=float, default=0.58)
     ap.add_argument("--halo", type=int, default=16, help="ghost columns per interior slab side (exchange every `halo` steps)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the NumPy CPU baseline (0 = skip)")
-    ap.add_argument("--fuse", type=int, default=0, choices=[0, 1],
-                    help="1: two steps per pass over the lattice (csrc/step_fused.hpp; fp32; bit-identical)")
+    ap.add_argument("--fuse", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="two steps per pass over the lattice (csrc/step_fused.hpp; fp32; bit-identical): -1 library "
+                         "default (on where it pays for one GPU, off for slabs), 0 off, 1 where it pays, 2 always")
     ap.add_argument("--fuse-chunk", type=int, default=0, help="columns per marching chunk (0 = chosen per mask)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
@@ -128,17 +129,17 @@ def main():
 
     if distributed:
         eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank, rank=rank, nranks=world, halo=args.halo)
-        if args.fuse:
+        if args.fuse >= 0 and args.dtype == "float32":
             eng.set_option("fuse_chunk", args.fuse_chunk)
-            eng.set_option("fuse_steps", 1)
+            eng.set_option("fuse_steps", args.fuse)
         ids = [wtpkg.Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         eng.comm_init_rank(ids[0])
     else:
         eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank)
-        if args.fuse:
+        if args.fuse >= 0 and args.dtype == "float32":
             eng.set_option("fuse_chunk", args.fuse_chunk)
-            eng.set_option("fuse_steps", 1)
+            eng.set_option("fuse_steps", args.fuse)
     eng.set_mask(mask)
     eng.init_equilibrium(args.u0)
 
@@ -169,7 +170,7 @@ def main():
     sites = nx_total * ny
     mlups = sites * args.steps / wall / 1e6
     bpl = BYTES_PER_LUP[args.dtype]
-    fused = bool(args.fuse and eng.get_option("fuse_active"))
+    fused = bool(eng.get_option("fuse_active"))
     launch_ms = dev_ms / args.steps                      # one step = one launch of k_step over the slab
     if fused:
         launch_ms *= 2.0                                 # one pass (k_step2 + the two list passes) = TWO steps
@@ -201,7 +202,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": measured_traffic(f"{nx_total}x{ny}_{args.dtype}") if not distributed else None,
+            "traffic": measured_traffic(f"{nx_total}x{ny}_{args.dtype}" + ("_fused" if fused else "")) if not distributed else None,
             "algorithmic_bytes_per_launch": bpl * sites_per_launch * (2 if fused else 1),
             "launch_ms": launch_ms,
         },

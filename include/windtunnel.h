@@ -84,8 +84,8 @@ const char *wt_version(void);
 
 /* Tuning knobs (no counterpart in the reference).  "fuse_steps" (0 / 1 = where it pays / 2 = always): advance TWO steps per pass
  * over the lattice where the flow is plain (temporal fusion in registers, csrc/step_fused.hpp);
- * results are bit-identical either way.  fp32 handles (whole lattices and slabs) with NY % 4 == 0; default off
- * (environment WT_FUSE2=1|2 sets it at wt_create).  "fuse_chunk": columns per marching chunk.
+ * results are bit-identical either way.  fp32 handles (whole lattices and slabs) with NY % 4 == 0.  Default: 1
+ * for whole-lattice handles, 0 for slab handles (environment WT_FUSE2=0|1|2 overrides at wt_create).  "fuse_chunk": columns per marching chunk.
  * wt_get_option also reports "fuse_active", "fuse_units", "fuse_tiles_single". */
 int wt_set_option(wt_handle *h, const char *name, double value);
 int wt_get_option(const wt_handle *h, const char *name, double *value);

@@ -41,7 +41,9 @@ def test_bench_json_contract():
 
 
 def test_bench_fused_flag_and_fp64():
-    d = _run("--fuse", "1", "--dtype", "float32")
-    assert d["config"]["fuse_steps"] in (0, 1)
+    d = _run("--fuse", "2", "--dtype", "float32")
+    assert d["config"]["fuse_steps"] == 1 and d["roofline"]["algorithmic_bytes_per_launch"] == 2 * 72 * 1024 * 512
+    d = _run("--fuse", "0")
+    assert d["config"]["fuse_steps"] == 0 and d["roofline"]["algorithmic_bytes_per_launch"] == 72 * 1024 * 512
     d = _run("--dtype", "float64")
     assert d["dtype"] == "f64" and d["roofline"]["algorithmic_bytes_per_launch"] == 144 * 1024 * 512

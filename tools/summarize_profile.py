@@ -17,6 +17,7 @@ src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 shutil.copy(glob.glob(os.path.join(src, "prof_trace/*/*_kernel_stats.csv"))[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 vals = {}
+fused = False
 for name in ("fetch", "write"):
     f = glob.glob(os.path.join(src, f"prof_{name}/*/*_counter_collection.csv"))[0]
     rows = [r for r in csv.DictReader(open(f)) if "k_step" in r["Kernel_Name"]]
@@ -24,14 +25,28 @@ for name in ("fetch", "write"):
         w = csv.writer(fh)
         w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value_KB", "Grid_Size", "VGPR_Count", "SGPR_Count"])
         for r in rows:
-            w.writerow([r["Kernel_Name"][:64], r["Counter_Name"], r["Counter_Value"], r["Grid_Size"], r["VGPR_Count"], r["SGPR_Count"]])
-    plain = [float(r["Counter_Value"]) for r in rows if "false" in r["Kernel_Name"].split("(")[0]]
-    vals[name] = sum(plain) / len(plain)
+            w.writerow([r["Kernel_Name"][:72], r["Counter_Name"], r["Counter_Value"], r["Grid_Size"], r["VGPR_Count"], r["SGPR_Count"]])
+    groups = {}
+    for r in rows:
+        head = r["Kernel_Name"].split("(")[0]
+        if "true" in head.replace("k_step_list<float, false", ""):      # skip the macro-emitting variants
+            if "k_step2<true>" in head or "k_step<float, true" in head or "k_step_list<float, true" in head:
+                continue
+        groups.setdefault(head, []).append(float(r["Counter_Value"]))
+    fused = any("k_step2" in k for k in groups)
+    if fused:      # one pass over the lattice = k_step2 + the two zone passes (each launched once per pass)
+        vals[name] = sum(sum(v) / len(v) for k, v in groups.items() if "k_step2" in k or "k_step_list" in k)
+    else:
+        v = [x for k, vv in groups.items() if "k_step<" in k for x in vv]
+        vals[name] = sum(v) / len(v)
 fetch, write = vals["fetch"] * 1024 * 2, vals["write"] * 1024
+if fused:
+    key += "_fused"
 path = os.path.join(dst, "pmc_traffic.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
 data[key] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
-             "kernel": "wt::k_step<float,false,...> (non-emitting step)",
+             "kernel": ("one pass = wt::k_step2<false> + k_step_list<...,1> + k_step_list<...,2> (TWO steps)" if fused
+                        else "wt::k_step<float,false,...> (non-emitting step)"),
              "source": f"profiles/{tag}_pmc_fetch_k_step.csv + {tag}_pmc_write_k_step.csv: separate --pmc passes; "
                        "FETCH_SIZE KB x1024 x2 (gfx950 correction, MI355X_MICROARCH.md HBM section); WRITE_SIZE KB x1024"}
 json.dump(data, open(path, "w"), indent=1)
