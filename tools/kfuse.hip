@@ -240,13 +240,15 @@ template <int NS> __device__ __forceinline__ VecN<NS> ldv(const float *p, bool u
         for (int v = 0; v < NS; v++) r.v[v] = x[v]; }
     return r;
 }
+static __device__ int g_nt_store = 0;   // experiment switch (set from the host)
 template <int NS> __device__ __forceinline__ void stv(float *p, const VecN<NS> &r)
 {
     typedef float VA __attribute__((ext_vector_type(NS)));
     VA x;
 #pragma unroll
     for (int v = 0; v < NS; v++) x[v] = r.v[v];
-    *reinterpret_cast<VA *>(p) = x;
+    if (g_nt_store) __builtin_nontemporal_store(x, reinterpret_cast<VA *>(p));
+    else *reinterpret_cast<VA *>(p) = x;
 }
 template <int NS> __device__ __forceinline__ void load9(const float *__restrict__ s, const Geom &g, long P, int col, int j0, VecN<NS> (&fin)[9])
 {
@@ -493,9 +495,9 @@ int main(int argc, char **argv)
         if (queue) { CK(hipMemsetAsync(counter, 0, 4, st)); blocks = 256L * wavesPerSimd; if (blocks * 4 > nunits) blocks = (nunits + 3) / 4; }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, a, b, g, ca, cb, L, nw, tau, U0, rev, counter);
     };
-    for (int L : {12, 24, 35}) {
-        vs.push_back({"baseline L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1, false, 0>, 4, false, L, 2, a, b, r); }, {}, 2});
-        vs.push_back({"counted-wait copies L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { launchg(k_step2g<4, false, 1, false, 2>, 4, false, L, 2, a, b, r); }, {}, 2});
+    for (int L : {24, 35}) {
+        vs.push_back({"plain stores L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { int z = 0; CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nt_store), &z, 4, 0, hipMemcpyHostToDevice, st)); launchg(k_step2g<4, false, 1, false, 0>, 4, false, L, 2, a, b, r); }, {}, 2});
+        vs.push_back({"nt stores L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { int z = 1; CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nt_store), &z, 4, 0, hipMemcpyHostToDevice, st)); launchg(k_step2g<4, false, 1, false, 0>, 4, false, L, 2, a, b, r); }, {}, 2});
     }
     const int reps = 4;
     for (int r = 0; r < rounds + 2; r++)
