@@ -60,6 +60,17 @@ def parse_args():
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(mask, steps, tau, u0, dtype):
     """NumPy transcription (the 'port') on the host cores; element-wise NumPy = 1 core."""
     import numpy as np
@@ -77,7 +88,7 @@ def cpu_baseline(mask, steps, tau, u0, dtype):
         "cores": 1,
         "kind": "port",
         "sample": f"{steps} steps of the same {nx}x{ny} {dtype} lattice and mask, oracle/lbm_numpy.py "
-                  f"(NumPy {np.__version__}, element-wise => single core; host has {os.cpu_count()} cpus), {dt:.1f} s",
+                  f"(NumPy {np.__version__}, element-wise => single core; host: {cpu_model()}, {os.cpu_count()} cpus), {dt:.1f} s",
     }
 
 
