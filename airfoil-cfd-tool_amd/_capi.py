@@ -23,7 +23,7 @@ WT_COMM_ID_BYTES = 128
 EXPORTS = (
     "wt_create", "wt_create_slab", "wt_destroy", "wt_get_info", "wt_last_error", "wt_version",
     "wt_set_option", "wt_get_option",
-    "wt_comm_unique_id", "wt_comm_init_rank", "wt_link_local", "wt_step_group",
+    "wt_comm_unique_id", "wt_comm_init_rank", "wt_comm_selftest", "wt_link_local", "wt_step_group",
     "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_read_f", "wt_write_f",
     "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_field", "wt_render_rgba", "wt_advect_tracers", "wt_sync",
 )
@@ -75,6 +75,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "wt_get_option": ([H, c_char_p, POINTER(c_double)], c_int),
         "wt_comm_unique_id": ([c_void_p], c_int),
         "wt_comm_init_rank": ([H, c_void_p], c_int),
+        "wt_comm_selftest": ([c_int, c_int], c_int),
         "wt_link_local": ([POINTER(H), c_int], c_int),
         "wt_step_group": ([POINTER(H), c_int, c_int, c_double, c_double], c_int),
         "wt_set_mask": ([H, c_void_p], c_int),
@@ -173,6 +174,10 @@ class Engine:
             raise ValueError("comm id must be WT_COMM_ID_BYTES long")
         buf = ctypes.create_string_buffer(comm_id, WT_COMM_ID_BYTES)
         _check(self._lib.wt_comm_init_rank(self._h, buf))
+
+    @staticmethod
+    def comm_selftest(device: int = 0, ny: int = 4096) -> None:
+        _check(load_library().wt_comm_selftest(int(device), int(ny)))
 
     @staticmethod
     def link_local(engines) -> None:

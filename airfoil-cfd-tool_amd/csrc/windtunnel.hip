@@ -701,6 +701,47 @@ extern "C" int wt_comm_init_rank(wt_handle *h, const void *id_in)
     return WT_OK;
 }
 
+// RCCL plumbing check on ONE GPU: a one-rank communicator, then the same grouped
+// ncclSend/ncclRecv pattern exchange_rccl uses (18 messages, to self), on a non-blocking stream.
+// Exercises the library's RCCL linkage and call sequence where no second GPU is available.
+extern "C" int wt_comm_selftest(int device, int ny)
+{
+    if (ny < 1 || ny > (1 << 20)) return fail(WT_ERR_ARG, "ny out of range");
+    HIP_TRY(hipSetDevice(device));
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(ncclCommInitRank(&comm, 1, id, 0));
+    const size_t count = (size_t)ny * 16;          // 16 ghost columns
+    float *src = nullptr, *dst = nullptr;
+    hipStream_t st = nullptr;
+    int rc = WT_OK;
+    std::vector<float> host(9 * count), back(9 * count);
+    for (size_t i = 0; i < host.size(); i++) host[i] = (float)(i % 9973) * 0.25f;
+    do {
+        if (hipMalloc((void **)&src, 9 * count * 4) != hipSuccess || hipMalloc((void **)&dst, 9 * count * 4) != hipSuccess) { rc = fail(WT_ERR_OOM, "selftest alloc"); break; }
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = fail(WT_ERR_HIP, "selftest stream"); break; }
+        if (hipMemcpy(src, host.data(), 9 * count * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(WT_ERR_HIP, "selftest upload"); break; }
+        if (hipMemset(dst, 0, 9 * count * 4) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(WT_ERR_HIP, "selftest memset"); break; }
+        ncclResult_t r = ncclGroupStart();
+        for (int k = 0; k < 9 && r == ncclSuccess; k++) {
+            r = ncclSend(src + k * count, count, ncclFloat32, 0, comm, st);
+            if (r == ncclSuccess) r = ncclRecv(dst + k * count, count, ncclFloat32, 0, comm, st);
+        }
+        const ncclResult_t re = ncclGroupEnd();
+        if (r == ncclSuccess) r = re;
+        if (r != ncclSuccess) { rc = fail(WT_ERR_RCCL, "selftest exchange failed: %s", ncclGetErrorString(r)); break; }
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = fail(WT_ERR_HIP, "selftest sync"); break; }
+        if (hipMemcpy(back.data(), dst, 9 * count * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(WT_ERR_HIP, "selftest download"); break; }
+        if (memcmp(host.data(), back.data(), 9 * count * 4) != 0) { rc = fail(WT_ERR_RCCL, "selftest: received data differ from sent data"); break; }
+    } while (0);
+    if (st) (void)hipStreamDestroy(st);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+    (void)ncclCommDestroy(comm);
+    return rc;
+}
+
 extern "C" int wt_link_local(wt_handle **hs, int n)
 {
     if (!hs || n < 2) return fail(WT_ERR_ARG, "need at least two slab handles");

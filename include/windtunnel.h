@@ -98,6 +98,9 @@ int wt_get_option(const wt_handle *h, const char *name, double *value);
 #define WT_COMM_ID_BYTES 128
 int wt_comm_unique_id(void *id_out);
 int wt_comm_init_rank(wt_handle *h, const void *id);
+/* One-GPU check of the RCCL plumbing: one-rank communicator + the grouped send/recv pattern of the
+ * ghost exchange (to self).  0 on success. */
+int wt_comm_selftest(int device, int ny);
 
 /* In-process transport: all slabs of one tunnel live in the calling process
  * (any mix of devices); ghost columns move by peer copies.  `hs` are the

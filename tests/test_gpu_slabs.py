@@ -161,3 +161,11 @@ def test_local_slab_wind_tunnel_one_process(pkg, oracle_c):
         np.testing.assert_allclose([wt.cl_smooth, wt.cd_smooth, wt.sep_frac], [ref.cl_smooth, ref.cd_smooth, ref.sep_frac], rtol=1e-12)
         assert np.array_equal(wt.render_rgba("vort"), ref.render_rgba("vort"))
         assert wt.stats().separation == ref.stats().separation
+
+
+def test_rccl_plumbing_selftest(pkg):
+    """ncclGetUniqueId / ncclCommInitRank / grouped ncclSend+ncclRecv from inside libwindtunnel on one GPU
+    (one-rank communicator, messages to self): the calls the multi-GPU ghost exchange is made of."""
+    pkg.Engine.comm_selftest(0, 4096)
+    ident = pkg.Engine.comm_unique_id()
+    assert len(ident) == 128 and any(ident)
