@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--u0", type=float, default=0.06)
     ap.add_argument("--tau", type=float, default=0.58)
     ap.add_argument("--halo", type=int, default=16, help="ghost columns per interior slab side (exchange every `halo` steps)")
-    ap.add_argument("--cpu-steps", type=int, default=4, help="steps of the NumPy CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the NumPy CPU baseline (0 = skip)")
     ap.add_argument("--fuse", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="two steps per pass over the lattice (csrc/step_fused.hpp; fp32; bit-identical): -1 library "
                          "default (on where it pays for one GPU, off for slabs), 0 off, 1 where it pays, 2 always")
