@@ -402,6 +402,108 @@ __global__ __launch_bounds__(256, MINW) void k_step2g(const float *__restrict__ 
     }
 }
 
+// ---- variant with hand-counted waits: the 9 prefetch loads are inline asm (invisible to hipcc's waitcnt
+// ---- pass, which otherwise drains the 9..27 stores of the iteration too), waited for with vmcnt(9) at the
+// ---- END of the iteration: the loads are older than at least 9 stores, so "all but the 9 youngest" covers
+// ---- them, and the main group of stores (issued last) stays in flight across the loop boundary.
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct In9 { f4v a[9]; };
+__device__ __forceinline__ void asm_load9(const float *__restrict__ s, const Geom &g, long P, int col, int j0, In9 &x)
+{
+    const long c = (long)col * g.pitch + j0;
+    const float *p0 = s + 0 * P + c, *p1 = s + 1 * P + c - g.pitch, *p3 = s + 3 * P + c + g.pitch;
+    const float *p2 = s + 2 * P + c - 1, *p5 = s + 5 * P + c - g.pitch - 1, *p6 = s + 6 * P + c + g.pitch - 1;
+    const float *p4 = s + 4 * P + c + 1, *p7 = s + 7 * P + c + g.pitch + 1, *p8 = s + 8 * P + c - g.pitch + 1;
+#define ALD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr) : "memory")
+    ALD(x.a[0], p0); ALD(x.a[1], p1); ALD(x.a[3], p3); ALD(x.a[2], p2); ALD(x.a[5], p5); ALD(x.a[6], p6); ALD(x.a[4], p4); ALD(x.a[7], p7); ALD(x.a[8], p8);
+#undef ALD
+}
+#define WAIT_IN9(N, x) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(x.a[0]), "+v"(x.a[1]), "+v"(x.a[2]), "+v"(x.a[3]), "+v"(x.a[4]), "+v"(x.a[5]), "+v"(x.a[6]), "+v"(x.a[7]), "+v"(x.a[8]) :: "memory")
+__device__ __forceinline__ void in9_to_vec(const In9 &x, V4 (&fin)[9])
+{
+#pragma unroll
+    for (int k = 0; k < 9; k++) { fin[k].v[0] = x.a[k][0]; fin[k].v[1] = x.a[k][1]; fin[k].v[2] = x.a[k][2]; fin[k].v[3] = x.a[k][3]; }
+}
+
+__device__ __forceinline__ void fused_iteration(const In9 &cur, const float *__restrict__ s, float *__restrict__ d, const Geom &g, long P, int c, int j0, int lane,
+                                                bool first_win, float tau, const float (&feq0)[9], V4 (&G158m)[3], V4 (&G024c)[3], V4 (&G158c)[3])
+{
+    V4 in[9], G[9];
+    in9_to_vec(cur, in);
+    collide_column(in, g, j0, tau, feq0, G);                       // step 1 of column c+1
+    V4 fin[9];
+    fin[0] = G024c[0]; fin[1] = G158m[0]; fin[3] = G[3];
+    fin[2] = from_below(G024c[1]); fin[5] = from_below(G158m[1]); fin[6] = from_below(G[6]);
+    fin[4] = from_above(G024c[2]); fin[8] = from_above(G158m[2]); fin[7] = from_above(G[7]);
+    V4 out[9];
+    collide_column(fin, g, j0, tau, feq0, out);                    // step 2 of column c
+    const long cc = (long)c * g.pitch + j0;
+    if (j0 + 3 < g.ny) {
+        // edge lanes first, the main group LAST (it is the one left in flight by the counted wait)
+        if (lane == 0 && !first_win) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(d + k * P + cc + 2) = make_float2(out[k].v[2], out[k].v[3]);
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(d + k * P + cc) = make_float2(out[k].v[0], out[k].v[1]);
+        }
+        if (lane != 63 && !(lane == 0 && !first_win)) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) vstore<float>(d + k * P + cc, out[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) G158m[k] = G158c[k];
+    G024c[0] = G[0]; G024c[1] = G[2]; G024c[2] = G[4];
+    G158c[0] = G[1]; G158c[1] = G[5]; G158c[2] = G[8];
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void k_step2a(const float *__restrict__ fs, float *__restrict__ fd, Geom g, int ca, int cb, int nwin, float tau, float U0, int rev)
+{
+    const int lane = threadIdx.x & 63;
+    const int nchunk = (cb - ca + L - 1) / L;
+    long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nunits = (long)nchunk * nwin;
+    if (unit >= nunits) return;
+    if (rev) unit = nunits - 1 - unit;
+    const int q = (int)(unit / nwin), w = (int)(unit % nwin);
+    const int ia = ca + q * L, ib = min(ia + L, cb);
+    const int j0 = w * 252 + lane * 4;
+    const float *s = fs + g.pitch;
+    float *d = fd + g.pitch;
+    const long P = g.plane;
+    float feq0[9];
+    feq_all<float>(1.0f, U0, 0.0f, feq0);
+    const bool first_win = (w == 0);
+    V4 G158m[3], G024c[3], G158c[3];
+    {
+        V4 in[9], G[9];
+        load_inputs(s, g, P, ia - 1, j0, in);
+        collide_column(in, g, j0, tau, feq0, G);
+        G158m[0] = G[1]; G158m[1] = G[5]; G158m[2] = G[8];
+        load_inputs(s, g, P, ia, j0, in);
+        collide_column(in, g, j0, tau, feq0, G);
+        G024c[0] = G[0]; G024c[1] = G[2]; G024c[2] = G[4];
+        G158c[0] = G[1]; G158c[1] = G[5]; G158c[2] = G[8];
+    }
+    In9 X, Y;
+    asm_load9(s, g, P, ia + 1, j0, X);
+    WAIT_IN9(0, X);                                  // nothing younger yet: plain drain before the loop
+    int c = ia;
+#pragma unroll 1
+    for (; c + 1 < ib; c += 2) {
+        asm_load9(s, g, P, c + 2, j0, Y);            // for iteration c+1
+        fused_iteration(X, s, d, g, P, c, j0, lane, first_win, tau, feq0, G158m, G024c, G158c);
+        WAIT_IN9(9, Y);                              // Y is older than the >= 9 stores just issued
+        asm_load9(s, g, P, (c + 3 <= ib) ? c + 3 : c + 2, j0, X);   // for iteration c+2 (harmless re-load at the end)
+        fused_iteration(Y, s, d, g, P, c + 1, j0, lane, first_win, tau, feq0, G158m, G024c, G158c);
+        WAIT_IN9(9, X);
+    }
+    if (c < ib) fused_iteration(X, s, d, g, P, c, j0, lane, first_win, tau, feq0, G158m, G024c, G158c);
+}
+
 int main(int argc, char **argv)
 {
     const int nx = argc > 1 ? atoi(argv[1]) : 4096, ny = argc > 2 ? atoi(argv[2]) : 4096, rounds = argc > 3 ? atoi(argv[3]) : 10;
@@ -481,6 +583,8 @@ int main(int argc, char **argv)
             check(variant == 0 ? "NS=2 queue L=12" : "NS=4 counted-wait L=12 rev");
         }
     }
+    { CK(hipMemset(f3, 0, lat)); CK(hipDeviceSynchronize()); launch2(k_step2a<24>, 24, f0, f3, 0); CK(hipStreamSynchronize(st)); CK(hipGetLastError()); check("counted waits L=24");
+      CK(hipMemset(f3, 0, lat)); CK(hipDeviceSynchronize()); launch2(k_step2a<35>, 35, f0, f3, 1); CK(hipStreamSynchronize(st)); check("counted waits L=35 rev"); }
     struct Var { std::string name; std::function<void(const float *, float *, int)> fn; std::vector<float> ms; int steps; };
     std::vector<Var> vs;
     vs.push_back({"production, 2 launches", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, f1, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(f1, b, macro, mask, tiles, tpc, g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
@@ -495,10 +599,9 @@ int main(int argc, char **argv)
         if (queue) { CK(hipMemsetAsync(counter, 0, 4, st)); blocks = 256L * wavesPerSimd; if (blocks * 4 > nunits) blocks = (nunits + 3) / 4; }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, a, b, g, ca, cb, L, nw, tau, U0, rev, counter);
     };
-    for (int L : {24, 35}) {
-        vs.push_back({"plain stores L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { int z = 0; CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nt_store), &z, 4, 0, hipMemcpyHostToDevice, st)); launchg(k_step2g<4, false, 1, false, 0>, 4, false, L, 2, a, b, r); }, {}, 2});
-        vs.push_back({"nt stores L=" + std::to_string(L), [&, L](const float *a, float *b, int r) { int z = 1; CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nt_store), &z, 4, 0, hipMemcpyHostToDevice, st)); launchg(k_step2g<4, false, 1, false, 0>, 4, false, L, 2, a, b, r); }, {}, 2});
-    }
+    vs.push_back({"counted waits (asm) L=12", [&](const float *a, float *b, int r) { launch2(k_step2a<12>, 12, a, b, r); }, {}, 2});
+    vs.push_back({"counted waits (asm) L=24", [&](const float *a, float *b, int r) { launch2(k_step2a<24>, 24, a, b, r); }, {}, 2});
+    vs.push_back({"counted waits (asm) L=35", [&](const float *a, float *b, int r) { launch2(k_step2a<35>, 35, a, b, r); }, {}, 2});
     const int reps = 4;
     for (int r = 0; r < rounds + 2; r++)
         for (auto &v : vs) {
