@@ -74,9 +74,92 @@ __device__ __forceinline__ void moments(const T (&f)[9], T &rho, T &ux, T &uy)
     uy = (f[2] + f[5] + f[6] - f[4] - f[7] - f[8]) / r;
 }
 
+// --------------------------------------------------------------------------------------
+// Division by the relaxation time (html:352-356: fin - (fin - feq)/tau, nine per site).
+//
+// tau is one value for the whole launch, so the generic IEEE expansion (v_div_scale x2,
+// v_rcp, five fma, v_div_fmas, v_div_fixup: 11 VALU instructions and one transcendental
+// issue slot, 44 % of the step's arithmetic) can be replaced by
+//     q0 = RN(x * r),  e = fma(-q0, tau, x)  (exact residual),  q = fma(e, r, q0),   r = RN(1/tau)
+// which returns the correctly rounded x/tau for every x of one binade iff it does for all
+// 2^23 significands (every operation commutes with an exact scaling by a power of two as
+// long as nothing over- or underflows).  The library PROVES this per tau before using it:
+// k_verify_fastdiv below compares the sequence with the IEEE quotient for all 2^23
+// significands on the device (a few microseconds, cached per tau); a tau that fails any of
+// them keeps the IEEE division.  Range argument for the scaling: after the clamp (html:344-350)
+// feq >= (1/36)*0.5*0.43 > 2^-8, so x = fin - feq is 0 or |x| >= 2^-32 (a multiple of
+// ulp(2^-9)), the residual is a multiple of 2^-80 — far from the subnormal range — and
+// x = +-0 gives +-0 in both forms (x = -0 cannot occur: fin - feq = -0 needs feq = +0).
+// Sites whose populations are not all below 2^100 in magnitude (blown-up or non-finite states)
+// take the IEEE division.
+// --------------------------------------------------------------------------------------
+struct FastDiv { float tau, rtau; };
+
+__device__ __forceinline__ float div_by_tau_fast(float x, const FastDiv &fd)
+{
+    const float q0 = x * fd.rtau;
+    const float e = __builtin_fmaf(-q0, fd.tau, x);
+    return __builtin_fmaf(e, fd.rtau, q0);
+}
+
+// exhaustive proof for one tau: counts significands whose fast quotient differs from x/tau
+__global__ void k_verify_fastdiv(float tau, float rtau, unsigned int *__restrict__ nbad)
+{
+    const FastDiv fd{tau, rtau};
+    unsigned int bad = 0;
+    for (unsigned int m = blockIdx.x * blockDim.x + threadIdx.x; m < (1u << 23); m += gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(0x3f800000u | m);            // [1, 2)
+        const float a = x / tau, b = div_by_tau_fast(x, fd);
+        bad += (__float_as_uint(a) != __float_as_uint(b));
+        const float xn = -x;                                         // the sequence is odd in x; checked anyway
+        const float an = xn / tau, bn = div_by_tau_fast(xn, fd);
+        bad += (__float_as_uint(an) != __float_as_uint(bn));
+    }
+    if (bad) atomicAdd(nbad, bad);
+}
+
 // html:335-359: moments, stability clamp, BGK relaxation.  `fin` are the
 // post-stream populations; returns the post-collision populations and the
 // clamped pre-collision (rho,ux,uy) the reference stores in texC.
+// FD = 1: fp32 only, division by tau through div_by_tau_fast (proved per tau, see above); 0: IEEE division;
+// 2: fast division without the magnitude guard (experiments only).
+template <int FD>
+__device__ __forceinline__ void collide_fd(const float (&fin)[9], const FastDiv &fd, float (&fo)[9], float &rho, float &ux, float &uy)
+{
+    float r, u, v;
+    moments(fin, r, u, v);
+    const float uMax = 0.35f, rhoMin = 0.5f, rhoMax = 2.0f;        // html:344
+    r = (r < rhoMin) ? rhoMin : r;
+    r = (rhoMax < r) ? rhoMax : r;
+    const float spd2 = u * u + v * v;
+    if (spd2 > uMax * uMax) {
+        const float k = uMax / wt_sqrt<float>(spd2);
+        u *= k;
+        v *= k;
+    }
+    float eq[9];
+    feq_all(r, u, v, eq);
+    bool fast = FD != 0;
+    if (FD == 1) {
+        // all |fin| < 2^100 (NaN compares false -> IEEE path)
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[0]), __builtin_fabsf(fin[1])), __builtin_fabsf(fin[2]));
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[3]), __builtin_fabsf(fin[4])), __builtin_fabsf(fin[5]));
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[6]), __builtin_fabsf(fin[7])), __builtin_fabsf(fin[8]));
+        const float m = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
+        fast = (m < 0x1p100f) && (r == r) && (spd2 == spd2);
+    }
+    if (fast) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) fo[k] = fin[k] - div_by_tau_fast(fin[k] - eq[k], fd);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) fo[k] = fin[k] - (fin[k] - eq[k]) / fd.tau;   // html:352-356
+    }
+    rho = r;
+    ux = u;
+    uy = v;
+}
+
 template <typename T>
 __device__ __forceinline__ void collide(const T (&fin)[9], T tau, T (&fo)[9], T &rho, T &ux, T &uy)
 {

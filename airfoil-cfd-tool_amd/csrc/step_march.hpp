@@ -1,0 +1,543 @@
+// step_march.hpp — TWO lattice steps per launch over the WHOLE lattice, body included (fp32).
+//
+// A wave owns a WINDOW of 256 rows (j, the fast axis) and marches along a CHUNK of columns (i).
+// Per iteration it (1) requests the 9 streamed input vectors of column c+2 (software prefetch),
+// (2) runs step 1 (STEP_FS main(), html:283-360) for column c+1 on the vectors requested one
+// iteration earlier, (3) runs step 2 for column c from the step-1 populations of columns c-1, c, c+1,
+// which never leave the register file (the +-1 shifts along j are lane shuffles, so the first and last
+// two rows of a window are not produced and windows advance by 252 rows), (4) stores 9 vectors.
+// HBM words per TWO site updates: 9 (L+2)/L + 9 instead of 18 + 18.
+//
+// Two instantiations share the code:
+//   * BODY = false — "plain" units: no solid site inside the unit's input footprint, no inlet / outlet
+//     column.  Straight-line arithmetic, nothing but populations is read.
+//   * BODY = true — every other unit (round 1 sent these through a third lattice in two single-step
+//     passes).  Each window-tile (column x, window w) has a class (k_classify_windows, wave ballots):
+//     FAST = no solid site in its 3 x 258 neighbourhood, SOLID = every own site solid, GENERAL = the rest;
+//     a unit reads the classes of its columns once (one byte per lane, two ballots -> two 64-bit scalars)
+//     and dispatches per column on a scalar bit test.  GENERAL tiles read one dword of solid flags and
+//     one dword of BOUNCE CODES per lane (bit k-1 = the upstream neighbour of direction k is solid;
+//     k_bounce_codes, once per mask upload) in place of the reference's nine mask texel reads
+//     (html:324-334); the sites' own populations (step 1: nine aligned 16-B loads, step 2: the step-1
+//     vectors of column c kept in registers) supply the bounced values.  The inlet (html:314-322) and
+//     outlet (html:301-312) columns are marched too: the outlet column NX-1 is emitted while column
+//     NX-2 is processed (its step-2 value is the step-1 state of NX-2).
+// Addressing: buffer instructions — one resource descriptor per lattice in scalar registers, ONE
+// per-lane byte offset for all 18 streams, the plane/column part of every address is a scalar add.
+// Every site is computed by exactly the arithmetic of k_step: results are bit-identical.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include "step_fast.hpp"
+
+namespace wt {
+
+static constexpr int MARCH_STRIDE = 252;         // rows a window advances by (256 loaded, 2 + 2 overlap)
+static constexpr int MARCH_MAX_BODY_CHUNK = 60;  // class bytes of columns ia-1 .. ib+1 must fit one wave
+
+enum : uint8_t { WC_FAST = 0, WC_GENERAL = 1, WC_SOLID = 2 };
+
+static inline int march_nwin(int ny) { return (ny - 2 + MARCH_STRIDE - 1) / MARCH_STRIDE; }
+
+// ------------------------------------------------------------------------------------------------
+// once per mask upload
+// ------------------------------------------------------------------------------------------------
+// wcls[w * ld + (x + 1)], x = -1 .. nxl (the two extra columns are FAST), ld = nxl + 2
+__global__ __launch_bounds__(256) void k_classify_windows(const uint8_t *__restrict__ mask, uint8_t *__restrict__ wcls, Geom g, int nwin)
+{
+    const int lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ld = g.nxl + 2;
+    if (tile >= (long)ld * nwin) return;
+    const int w = (int)(tile / ld), x = (int)(tile % ld) - 1;
+    uint8_t cls = WC_FAST;
+    if (x >= 0 && x < g.nxl) {
+        const int j0 = w * MARCH_STRIDE;
+        const uint8_t *m = mask + g.pitch;
+        int nb = 0, own_all = 1;
+        for (int jj = j0 - 1 + lane; jj <= j0 + 256; jj += 64) {
+            if (jj < 0 || jj >= g.ny) continue;
+            const int a = m[(long)(x - 1) * g.pitch + jj], b = m[(long)x * g.pitch + jj], c = m[(long)(x + 1) * g.pitch + jj];
+            nb |= a | b | c;
+            if (jj >= j0 && jj < j0 + 256) own_all &= (b != 0);
+        }
+        const bool any_nb = __ballot(nb != 0) != 0ULL;
+        const bool all_own = __ballot(own_all == 0) == 0ULL;
+        cls = !any_nb ? WC_FAST : (all_own ? WC_SOLID : WC_GENERAL);
+    }
+    if (lane == 0) wcls[(long)w * ld + x + 1] = cls;
+}
+
+// bcode[x * pitch + j], bit k-1 set <=> site (x - ex_k, j - ey_k) is solid (k = 1..8); 0 on rows 0 / NY-1;
+// 0xFF on solid sites
+__global__ __launch_bounds__(256) void k_bounce_codes(const uint8_t *__restrict__ mask, uint8_t *__restrict__ bcode, Geom g)
+{
+    const uint8_t *m = mask + g.pitch;
+    const long total = (long)g.nxl * g.pitch;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int x = (int)(t / g.pitch), j = (int)(t % g.pitch);
+        unsigned code = 0;
+        if (j < g.ny && m[(long)x * g.pitch + j]) code = 0xffu;       // a solid site "bounces" every direction: fin[k] = own[opp(k)]
+        else if (j >= 1 && j < g.ny - 1) {
+#pragma unroll
+            for (int k = 1; k < 9; k++)
+                if (m[(long)(x - ex_of(k)) * g.pitch + (j - ey_of(k))]) code |= 1u << (k - 1);
+        }
+        bcode[t] = (uint8_t)code;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// units
+// ------------------------------------------------------------------------------------------------
+struct MarchUnit { int ia, ib, w, flags; };      // marched columns [ia, ib), window; flags bit 0: emit the outlet column ib with column ib-1
+enum { MU_OUTLET_AFTER = 1 };
+
+struct MarchParams {
+    const float *fs;
+    float *fd;
+    float *macro;
+    const uint8_t *mask;       // padded byte mask (column -1 first)
+    const uint8_t *bcode;      // bounce codes, column 0 first
+    const uint8_t *wcls;       // window-tile classes [nwin][nxl + 2]
+    const MarchUnit *units;
+    int nunits;
+    Geom g;
+    unsigned lat_bytes;        // bytes of one lattice (9 planes) — below 4 GiB
+    FastDiv fdv;
+    float U0;
+    int rev;
+};
+
+typedef Vec<float> V4;
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ V4 v4_splat(float x) { V4 r; r.v[0] = x; r.v[1] = x; r.v[2] = x; r.v[3] = x; return r; }
+
+// value at j-1 / j+1 taken from the neighbouring lane (window-edge rows get garbage: never stored)
+__device__ __forceinline__ V4 m_below(const V4 &r) { V4 o; o.v[0] = lane_up(r.v[3]); o.v[1] = r.v[0]; o.v[2] = r.v[1]; o.v[3] = r.v[2]; return o; }
+__device__ __forceinline__ V4 m_above(const V4 &r) { V4 o; o.v[0] = r.v[1]; o.v[1] = r.v[2]; o.v[2] = r.v[3]; o.v[3] = lane_down(r.v[0]); return o; }
+
+// buffer addressing: rsrc = whole lattice; voff = the lane's byte offset (j0 * 4, loop-invariant);
+// soff = scalar byte offset of (plane, column, row shift)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t march_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ V4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);     // aux 2 = nt (read once per pass)
+    V4 o;
+    o.v[0] = __uint_as_float(x.x); o.v[1] = __uint_as_float(x.y); o.v[2] = __uint_as_float(x.z); o.v[3] = __uint_as_float(x.w);
+    return o;
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const V4 &v)
+{
+    u4v x;
+    x.x = __float_as_uint(v.v[0]); x.y = __float_as_uint(v.v[1]); x.z = __float_as_uint(v.v[2]); x.w = __float_as_uint(v.v[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+}
+__device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b)
+{
+    u2v x;
+    x.x = __float_as_uint(a); x.y = __float_as_uint(b);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+}
+
+struct MarchAddr {
+    __amdgpu_buffer_rsrc_t rs, rd, rm;   // source lattice, destination lattice, macro planes
+    unsigned voff;                       // j0 * 4
+    unsigned P4, pitch4, mp4;            // plane / column / macro-plane strides in bytes
+};
+
+// byte offset of (plane k, local column col, row shift dj) from the lattice base (one pad column in front)
+__device__ __forceinline__ unsigned lat_off(const MarchAddr &a, int k, int col, int dj)
+{
+    return (unsigned)k * a.P4 + (unsigned)(col + 1) * a.pitch4 + (unsigned)(dj * 4);
+}
+
+// the nine streamed (pulled) input vectors of column `col`
+__device__ __forceinline__ void march_load_stream(const MarchAddr &a, int col, V4 (&fin)[9])
+{
+    fin[0] = bload(a.rs, a.voff, lat_off(a, 0, col, 0));
+    fin[1] = bload(a.rs, a.voff, lat_off(a, 1, col - 1, 0));
+    fin[3] = bload(a.rs, a.voff, lat_off(a, 3, col + 1, 0));
+    fin[2] = bload(a.rs, a.voff, lat_off(a, 2, col, -1));
+    fin[5] = bload(a.rs, a.voff, lat_off(a, 5, col - 1, -1));
+    fin[6] = bload(a.rs, a.voff, lat_off(a, 6, col + 1, -1));
+    fin[4] = bload(a.rs, a.voff, lat_off(a, 4, col, 1));
+    fin[7] = bload(a.rs, a.voff, lat_off(a, 7, col + 1, 1));
+    fin[8] = bload(a.rs, a.voff, lat_off(a, 8, col - 1, 1));
+}
+
+// the nine populations of the sites of column `col` themselves
+__device__ __forceinline__ void march_load_own(const MarchAddr &a, int col, V4 (&own)[9])
+{
+#pragma unroll
+    for (int k = 0; k < 9; k++) own[k] = bload(a.rs, a.voff, lat_off(a, k, col, 0));
+}
+
+// collide 4 sites per lane
+template <int FD, bool WANT_MACRO>
+__device__ __forceinline__ void march_collide(const V4 (&fin)[9], const FastDiv &fdv, V4 (&G)[9], V4 (&mac)[3])
+{
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        float a[9], o[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+        collide_fd<FD>(a, fdv, o, rho, ux, uy);
+#pragma unroll
+        for (int k = 0; k < 9; k++) G[k].v[v] = o[k];
+        if (WANT_MACRO) { mac[0].v[v] = rho; mac[1].v[v] = ux; mac[2].v[v] = uy; }
+    }
+}
+
+// rows 0 and NY-1 carry the far-field populations (html:314-322); only called for windows that hold one of them
+template <bool WANT_MACRO>
+__device__ __forceinline__ void march_far_rows(int j0, int ny, float U0, const float (&feq0)[9], V4 (&G)[9], V4 (&mac)[3])
+{
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const int j = j0 + v;
+        const bool far = (j == 0) || (j == ny - 1);
+#pragma unroll
+        for (int k = 0; k < 9; k++) G[k].v[v] = far ? feq0[k] : G[k].v[v];
+        if (WANT_MACRO) { mac[0].v[v] = far ? 1.0f : mac[0].v[v]; mac[1].v[v] = far ? U0 : mac[1].v[v]; mac[2].v[v] = far ? 0.0f : mac[2].v[v]; }
+    }
+}
+
+// GENERAL tile, before the collision: half-way bounce-back (html:324-334) as an in-place select —
+// direction k of a site takes the site's OWN population opp(k) where the bounce code has bit k-1 set.
+// `own(k)` yields the vector of the sites' own populations of direction k (step 1: an aligned load,
+// step 2: the step-1 vector of column c held in registers); one vector is live at a time.
+template <typename OWN>
+__device__ __forceinline__ void march_bounce(V4 (&fin)[9], uint32_t code4, OWN own)
+{
+#pragma unroll
+    for (int k = 1; k < 9; k++) {
+        const V4 o = own(opp_of(k));
+#pragma unroll
+        for (int v = 0; v < 4; v++) fin[k].v[v] = ((code4 >> (8 * v + k - 1)) & 1u) ? o.v[v] : fin[k].v[v];
+    }
+}
+
+// GENERAL tile, the collision itself.  `fin` went through march_bounce with code 0xFF on solid sites, i.e. a solid
+// site's fin[k] already IS its own population opp(k) — the value the reference stores for it (html:287-294) — so the
+// solid select needs no further loads.  Reference order: solid, far field (html:314-322), interior (html:335-359).
+template <int FD, bool WANT_MACRO>
+__device__ __forceinline__ void march_collide_general(const V4 (&fin)[9], uint32_t solid4, int j0, int ny, const FastDiv &fdv, float U0,
+                                                      const float (&feq0)[9], V4 (&G)[9], V4 (&mac)[3])
+{
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        float a[9], o[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+        collide_fd<FD>(a, fdv, o, rho, ux, uy);
+        const bool solid = ((solid4 >> (8 * v)) & 0xffu) != 0;
+        const int j = j0 + v;
+        const bool far = (j == 0) || (j == ny - 1);
+#pragma unroll
+        for (int k = 0; k < 9; k++) G[k].v[v] = solid ? a[k] : (far ? feq0[k] : o[k]);
+        if (WANT_MACRO) {
+            mac[0].v[v] = (solid || far) ? 1.0f : rho;
+            mac[1].v[v] = solid ? 0.0f : (far ? U0 : ux);
+            mac[2].v[v] = (solid || far) ? 0.0f : uy;
+        }
+    }
+}
+
+// after the collision: solid sites carry their own populations reversed (html:287-294), macro (1,0,0)
+template <bool WANT_MACRO, typename OWN>
+__device__ __forceinline__ void march_solid(V4 (&G)[9], V4 (&mac)[3], uint32_t solid4, OWN own)
+{
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const V4 o = own(opp_of(k));
+#pragma unroll
+        for (int v = 0; v < 4; v++) G[k].v[v] = ((solid4 >> (8 * v)) & 0xffu) ? o.v[v] : G[k].v[v];
+    }
+    if (WANT_MACRO) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const bool solid = ((solid4 >> (8 * v)) & 0xffu) != 0;
+            mac[0].v[v] = solid ? 1.0f : mac[0].v[v]; mac[1].v[v] = solid ? 0.0f : mac[1].v[v]; mac[2].v[v] = solid ? 0.0f : mac[2].v[v];
+        }
+    }
+}
+
+// outlet column (html:301-312): macro = moments of the copied populations, not clamped
+__device__ __forceinline__ void march_outlet_macro(const V4 (&q9)[9], V4 (&mac)[3])
+{
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        float q[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) q[k] = q9[k].v[v];
+        moments(q, rho, ux, uy);
+        mac[0].v[v] = rho; mac[1].v[v] = ux; mac[2].v[v] = uy;
+    }
+}
+
+// store the window's output rows of column `col`: lane 0 keeps rows J0+2.. (unless first window), lane 63 rows ..J0+253
+template <bool EMIT>
+__device__ __forceinline__ void march_store(const MarchAddr &a, int ny, int col, int j0, int lane, bool first_win, const V4 (&out)[9], const V4 (&mac)[3])
+{
+    if (j0 + 3 >= ny) return;
+    const unsigned mo = (unsigned)col * a.pitch4;
+    if (lane == 0 && !first_win) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) bstore2(a.rd, a.voff, lat_off(a, k, col, 2), out[k].v[2], out[k].v[3]);
+        if (EMIT)
+#pragma unroll
+            for (int q = 0; q < 3; q++) bstore2(a.rm, a.voff, (unsigned)q * a.mp4 + mo + 8u, mac[q].v[2], mac[q].v[3]);
+    } else if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) bstore2(a.rd, a.voff, lat_off(a, k, col, 0), out[k].v[0], out[k].v[1]);
+        if (EMIT)
+#pragma unroll
+            for (int q = 0; q < 3; q++) bstore2(a.rm, a.voff, (unsigned)q * a.mp4 + mo, mac[q].v[0], mac[q].v[1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) bstore(a.rd, a.voff, lat_off(a, k, col, 0), out[k]);
+        if (EMIT)
+#pragma unroll
+            for (int q = 0; q < 3; q++) bstore(a.rm, a.voff, (unsigned)q * a.mp4 + mo, mac[q]);
+    }
+}
+
+// Step 1 of column x -> G (all nine directions).  `in` holds the streamed inputs of column x (modified in place).
+template <bool BODY, int FD>
+__device__ __forceinline__ void march_step1(const MarchParams &p, const MarchAddr &a, int x, int j0, bool far_win, bool nonfast, bool allsolid,
+                                            const float (&feq0)[9], V4 (&in)[9], V4 (&G)[9])
+{
+    V4 mac[3];
+    if (BODY) {
+        const Geom &g = p.g;
+        const int gi = x + g.gi0;
+        auto own = [&](int k) { return bload(a.rs, a.voff, lat_off(a, k, x, 0)); };
+        if (__builtin_expect(gi <= 0 || gi >= g.nx_g - 1 || nonfast, 0)) {
+            // rare paths (scalar branches): inlet / outlet columns, body surface, body interior
+            uint32_t solid4 = 0, code4 = 0;
+            if (nonfast) {
+                solid4 = *reinterpret_cast<const uint32_t *>(p.mask + (long)(x + 1) * g.pitch + j0);
+                code4 = *reinterpret_cast<const uint32_t *>(p.bcode + (long)x * g.pitch + j0);
+            }
+            const bool any_solid = __ballot(solid4 != 0) != 0ULL;
+            if (gi <= 0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) G[k] = v4_splat(feq0[k]);
+            } else if (gi >= g.nx_g - 1) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) G[k] = bload(a.rs, a.voff, lat_off(a, k, x - 1, 0));
+            } else if (allsolid) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) G[k] = own(opp_of(k));
+                return;
+            } else {
+                march_bounce(in, code4, own);
+                march_collide_general<FD, false>(in, solid4, j0, g.ny, p.fdv, p.U0, feq0, G, mac);
+                return;
+            }
+            if (any_solid) march_solid<false>(G, mac, solid4, own);      // inlet / outlet columns with solid sites
+            return;
+        }
+    }
+    march_collide<FD, false>(in, p.fdv, G, mac);
+    if (far_win) march_far_rows<false>(j0, p.g.ny, p.U0, feq0, G, mac);
+}
+
+template <bool BODY, bool EMIT, int FD, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
+{
+    const Geom &g = p.g;
+    const int lane = threadIdx.x & 63;
+    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= p.nunits) return;
+    if (p.rev) u = p.nunits - 1 - u;
+    const MarchUnit un = p.units[u];
+    const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
+    const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
+    const int row0 = w * MARCH_STRIDE;
+    const int j0 = row0 + lane * 4;
+    const bool first_win = (w == 0);
+    const bool far_win = first_win || (row0 + 256 >= g.ny);      // the window holds row 0 or row NY-1
+    MarchAddr a;
+    a.rs = march_rsrc(p.fs, p.lat_bytes);
+    a.rd = march_rsrc(p.fd, p.lat_bytes);
+    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
+    a.voff = (unsigned)j0 * 4u;
+    a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
+    float feq0[9];
+    feq_all<float>(1.0f, p.U0, 0.0f, feq0);                       // far-field populations (html:314-322)
+
+    // BODY: classes of columns ia-1 .. ib (lane l <-> column ia-1+l): two 64-bit scalars
+    unsigned long long nonfast_m = 0, solid_m = 0;
+    if (BODY) {
+        const int n = ib - ia + 2;
+        uint8_t cls = WC_FAST;
+        if (lane < n) cls = p.wcls[(long)w * (g.nxl + 2) + ia + lane];
+        nonfast_m = __ballot(cls != WC_FAST);
+        solid_m = __ballot(cls == WC_SOLID);
+    }
+#define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 1)) & 1ULL) != 0)
+#define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 1)) & 1ULL) != 0)
+#define STEP1(x, in, G) march_step1<BODY, FD>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+
+    V4 G158m[3];                 // step-1 populations 1,5,8 of column c-1
+    V4 Gc[9];                    // step-1 populations of column c (BODY = false: only 0,2,4 and 1,5,8 stay live)
+    V4 in[9], G[9], mac[3];
+    if (!BODY || ia + g.gi0 > 0) {        // column ia-1 exists (ia = 0 on the inlet side: its step 2 is the far field)
+        march_load_stream(a, ia - 1, in);
+        STEP1(ia - 1, in, G);
+        G158m[0] = G[1]; G158m[1] = G[5]; G158m[2] = G[8];
+    } else {
+        G158m[0] = v4_splat(feq0[1]); G158m[1] = v4_splat(feq0[5]); G158m[2] = v4_splat(feq0[8]);
+    }
+    march_load_stream(a, ia, in);
+    STEP1(ia, in, Gc);
+    march_load_stream(a, ia + 1, in);
+#pragma unroll 1
+    for (int c = ia; c < ib; c++) {
+        V4 nxt[9];
+        march_load_stream(a, (c + 2 <= ib) ? c + 2 : c + 1, nxt);             // prefetch (last one: harmless re-load)
+        STEP1(c + 1, in, G);                                                  // step 1 of column c+1
+        // ---- step 2 of column c
+        V4 fin[9], out[9];
+        fin[0] = Gc[0]; fin[1] = G158m[0]; fin[3] = G[3];
+        fin[2] = m_below(Gc[2]); fin[5] = m_below(G158m[1]); fin[6] = m_below(G[6]);
+        fin[4] = m_above(Gc[4]); fin[8] = m_above(G158m[2]); fin[7] = m_above(G[7]);
+        bool plain = true;
+        if (BODY) {
+            const int gi = c + g.gi0;
+            const bool nf = NONFAST(c);
+            if (__builtin_expect(gi <= 0 || nf, 0)) {
+                plain = false;
+                auto ownc = [&](int k) { return Gc[k]; };
+                uint32_t solid4 = 0, code4 = 0;
+                if (nf) {
+                    solid4 = *reinterpret_cast<const uint32_t *>(p.mask + (long)(c + 1) * g.pitch + j0);
+                    code4 = *reinterpret_cast<const uint32_t *>(p.bcode + (long)c * g.pitch + j0);
+                }
+                const bool any_solid = __ballot(solid4 != 0) != 0ULL;
+                if (gi <= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) out[k] = v4_splat(feq0[k]);
+                    if (EMIT) { mac[0] = v4_splat(1.0f); mac[1] = v4_splat(p.U0); mac[2] = v4_splat(0.0f); }
+                } else if (ALLSOLID(c)) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) out[k] = Gc[k];        // every site is overwritten by march_solid below
+                    if (EMIT) { mac[0] = v4_splat(1.0f); mac[1] = v4_splat(0.0f); mac[2] = v4_splat(0.0f); }
+                } else {
+                    march_bounce(fin, code4, ownc);
+                    march_collide_general<FD, EMIT>(fin, solid4, j0, g.ny, p.fdv, p.U0, feq0, out, mac);
+                }
+                if (any_solid && (gi <= 0 || ALLSOLID(c))) march_solid<EMIT>(out, mac, solid4, ownc);
+            }
+        }
+        if (plain) {
+            march_collide<FD, EMIT>(fin, p.fdv, out, mac);
+            if (far_win) march_far_rows<EMIT>(j0, g.ny, p.U0, feq0, out, mac);
+        }
+        march_store<EMIT>(a, g.ny, c, j0, lane, first_win, out, mac);
+        if (BODY && __builtin_expect((uflags & MU_OUTLET_AFTER) && c + 1 == ib, 0)) {
+            // outlet column NX-1 (html:301-312): its step-2 value is the step-1 state of column NX-2 (= Gc), its own
+            // step-1 state (solid sites only) is G
+            uint32_t solid4 = 0;
+            if (NONFAST(c + 1)) solid4 = *reinterpret_cast<const uint32_t *>(p.mask + (long)(c + 2) * g.pitch + j0);
+            auto ownp = [&](int k) { return G[k]; };
+#pragma unroll
+            for (int k = 0; k < 9; k++) out[k] = Gc[k];
+            if (EMIT) march_outlet_macro(Gc, mac);
+            if (__ballot(solid4 != 0) != 0ULL) march_solid<EMIT>(out, mac, solid4, ownp);
+            march_store<EMIT>(a, g.ny, c + 1, j0, lane, first_win, out, mac);
+        }
+        G158m[0] = Gc[1]; G158m[1] = Gc[5]; G158m[2] = Gc[8];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { Gc[k] = G[k]; in[k] = nxt[k]; }
+    }
+#undef NONFAST
+#undef ALLSOLID
+#undef STEP1
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: the unit lists of one mask
+// ------------------------------------------------------------------------------------------------
+// Marched column range of a handle: global edges are part of the march (inlet column 0; outlet column
+// emitted with NX-2), local slab edges are not (their ghost columns lose two columns of validity per pass).
+struct MarchRange { int i_begin, i_end, outlet_after; };
+static inline MarchRange march_range(const Geom &g)
+{
+    MarchRange r;
+    r.i_begin = (g.gi0 == 0) ? 0 : 1;
+    r.i_end = g.nxl - 1;
+    r.outlet_after = (g.gi0 + g.nxl == g.nx_g) ? 1 : 0;
+    return r;
+}
+
+struct MarchPlan {
+    std::vector<MarchUnit> plain, body;
+    int nwin = 0;
+};
+
+// wcls: host copy of the window-tile classes [nwin][nxl+2].  Per window, the marched columns split into maximal
+// runs: a column belongs to a PLAIN run when the tiles x-1, x, x+1 are FAST and neither x-1 nor x+1 is an inlet /
+// outlet column, else to a BODY run (split = false: one BODY run per window).  A run is cut into units of about
+// equal COST, at most Lp (plain) or Lb (body) cost units each: a FAST column costs 1, any other column 1 + alpha
+// (its step 1 waits for nine more loads); all units of a launch are resident at once, so the launch takes as long
+// as its most expensive unit.
+static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int Lp, int Lb, bool split = true, double alpha = 1.0)
+{
+    MarchPlan pl;
+    const int nwin = march_nwin(g.ny), ld = g.nxl + 2;
+    pl.nwin = nwin;
+    const MarchRange r = march_range(g);
+    if (Lb > MARCH_MAX_BODY_CHUNK) Lb = MARCH_MAX_BODY_CHUNK;
+    if (Lp < 1) Lp = 1;
+    if (Lb < 1) Lb = 1;
+    for (int w = 0; w < nwin; w++) {
+        const uint8_t *c = wcls + (size_t)w * ld + 1;       // c[x], x = -1 .. nxl
+        auto is_plain = [&](int x) {
+            const int gi = x + g.gi0;
+            if (!split) return false;                        // one list: every unit through the BODY kernel
+            if (gi <= 1 || gi >= g.nx_g - 2) return false;   // step 1 of x-1 / x+1 must not be the inlet / outlet column
+            return c[x - 1] == WC_FAST && c[x] == WC_FAST && c[x + 1] == WC_FAST;
+        };
+        auto cost = [&](int x) { return c[x] == WC_FAST ? 1.0 : 1.0 + alpha; };
+        auto cut = [&](std::vector<MarchUnit> &dst, int a, int b, int Lmax, int maxcols, bool outlet) {
+            double total = 0.0;
+            for (int x = a; x < b; x++) total += cost(x);
+            int parts = (int)((total + Lmax - 1e-9) / Lmax);
+            if (parts < 1) parts = 1;
+            const double target = total / parts;
+            int ia = a;
+            double acc = 0.0;
+            int done = 0;
+            for (int x = a; x < b; x++) {
+                acc += cost(x);
+                const bool last = (x + 1 == b);
+                if (last || acc >= target * (done + 1) - 1e-9 || x + 1 - ia >= maxcols) {
+                    dst.push_back(MarchUnit{ia, x + 1, w, (outlet && last) ? MU_OUTLET_AFTER : 0});
+                    ia = x + 1;
+                    done++;
+                }
+            }
+        };
+        int x = r.i_begin;
+        while (x < r.i_end) {
+            const bool pln = is_plain(x);
+            int e = x + 1;
+            while (e < r.i_end && is_plain(e) == pln) e++;
+            if (pln) cut(pl.plain, x, e, Lp, 1 << 30, false);
+            else cut(pl.body, x, e, Lb, MARCH_MAX_BODY_CHUNK, r.outlet_after && e == r.i_end);
+            x = e;
+        }
+    }
+    return pl;
+}
+
+}  // namespace wt

@@ -13,12 +13,13 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/windtunnel.h"
 #include "kernels.hpp"
 #include "step_fast.hpp"
-#include "step_fused.hpp"
+#include "step_march.hpp"
 
 using namespace wt;
 
@@ -89,18 +90,25 @@ struct wt_handle {
     int transport = TR_NONE;
     ncclComm_t comm = nullptr;
     wt_handle *peer_l = nullptr, *peer_r = nullptr;   // TR_LOCAL
-    // two-steps-per-launch mode (step_fused.hpp); whole-lattice fp32 handles only
+    // two-steps-per-launch mode (step_march.hpp); fp32 handles with NY % 4 == 0
     bool fuse = false;
     bool fuse_force = false;             // fuse_steps = 2: also when the lattice is too small for it to pay
-    int fuse_chunk = 0;                  // 0 = chosen per mask (auto_fuse_chunk)
+    int fuse_chunk = 0;                  // plain-unit cost limit; 0 = chosen from the lattice size
+    int fuse_chunk_body = 0;             // body-unit cost limit; 0 = automatic
+    int fuse_split = 1;                  // 1: plain units through the lean kernel, the rest through the BODY kernel; 0: one list
     bool fuse_ready = false;
     int fuse_chunk_used = 0;
-    void *f_tmp = nullptr;               // third lattice for the non-fusable zone
-    FuseUnit *d_units = nullptr;
-    int *d_t1 = nullptr, *d_t2 = nullptr;
-    int n_units = 0, n_t1 = 0, n_t2 = 0, n_win = 0;
-    uint8_t *wtiles = nullptr;           // classes of the window-aligned tiles (nxl x n_win)
-    std::vector<uint8_t> host_mask;      // copy of the last mask (plan rebuilds when an option changes)
+    uint8_t *bcode = nullptr;            // bounce codes, (nxl+2) * pitch
+    uint8_t *wcls = nullptr;             // window-tile classes, nwin * (nxl+2)
+    MarchUnit *d_units = nullptr;        // plain units first, then body units
+    size_t units_cap = 0;
+    int n_plain = 0, n_body = 0, n_win = 0, body_cols = 0;
+    std::vector<uint8_t> host_wcls;
+    // fast division by tau (d2q9.hpp): proved per tau on the device before it is used
+    unsigned int *d_nbad = nullptr;
+    float fd_tau = 0.0f;
+    bool fd_checked = false, fd_ok = false;
+    bool fast_div = true;                // option "fast_div"
 };
 
 static const int kReduceBlocks = 1024;
@@ -215,6 +223,10 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
         if (e) { h->fuse = atoi(e) != 0; h->fuse_force = atoi(e) >= 2; }
         const char *c = getenv("WT_FUSE_CHUNK");
         if (c && atoi(c) >= 0) h->fuse_chunk = atoi(c);
+        const char *sp = getenv("WT_FUSE_SPLIT");
+        if (sp) h->fuse_split = atoi(sp) != 0;
+        const char *fdv = getenv("WT_FAST_DIV");
+        if (fdv) h->fast_div = atoi(fdv) != 0;
     }
     *out = h;
     return WT_OK;
@@ -245,11 +257,10 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->mask) (void)hipFree(h->mask);
     if (h->tiles) (void)hipFree(h->tiles);
     if (h->stage) (void)hipFree(h->stage);
-    if (h->f_tmp) (void)hipFree(h->f_tmp);
+    if (h->bcode) (void)hipFree(h->bcode);
+    if (h->wcls) (void)hipFree(h->wcls);
     if (h->d_units) (void)hipFree(h->d_units);
-    if (h->d_t1) (void)hipFree(h->d_t1);
-    if (h->d_t2) (void)hipFree(h->d_t2);
-    if (h->wtiles) (void)hipFree(h->wtiles);
+    if (h->d_nbad) (void)hipFree(h->d_nbad);
     if (h->partials) (void)hipFree(h->partials);
     if (h->partials_host) (void)hipHostFree(h->partials_host);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -285,56 +296,86 @@ extern "C" int wt_sync(wt_handle *h)
 }
 
 // ------------------------------------------------------------------------------------------
-// two-steps-per-launch plan
+// two-steps-per-launch plan (step_march.hpp)
 // ------------------------------------------------------------------------------------------
-// whole lattices and column slabs alike (a slab plans over its LOCAL columns, ghosts included)
-static bool fuse_eligible(const wt_handle *h) { return h->dtype == WT_F32 && h->g.ny % 4 == 0 && h->g.nxl >= 8; }
-
-template <typename U>
-static int upload_vec(U **dptr, const std::vector<U> &v, wt_handle *h)
+// whole lattices and column slabs alike (a slab plans over its LOCAL columns, ghosts included); the
+// marching kernels address a lattice through one 32-bit buffer descriptor
+static bool fuse_eligible(const wt_handle *h)
 {
-    if (*dptr) { HIP_TRY(hipFree(*dptr)); *dptr = nullptr; }
-    if (v.empty()) return WT_OK;
-    HIP_TRY(hipMalloc((void **)dptr, v.size() * sizeof(U)));
-    HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice));
-    (void)h;
-    return WT_OK;
+    return h->dtype == WT_F32 && h->g.ny % 4 == 0 && h->g.nxl >= 8 && (unsigned long long)9 * h->g.plane * 4ULL < (1ULL << 32);
 }
 
+// Classes, bounce codes and the unit lists of the current mask.  Everything but the two cuts of the
+// column ranges runs on the device; the host reads nwin x (nxl+2) class bytes back.
 static int rebuild_fuse_plan(wt_handle *h)
 {
     h->fuse_ready = false;
-    if (!h->fuse || !fuse_eligible(h) || h->host_mask.empty()) return WT_OK;
+    h->n_plain = h->n_body = h->body_cols = 0;
+    if (!h->fuse || !fuse_eligible(h) || !h->mask_set) return WT_OK;
+    const Geom &g = h->g;
+    const int nwin = march_nwin(g.ny);
+    const size_t wbytes = (size_t)nwin * (g.nxl + 2), cbytes = (size_t)(g.nxl + 2) * g.pitch;
+    if (!h->wcls || h->n_win != nwin) {
+        if (h->wcls) { HIP_TRY(hipFree(h->wcls)); h->wcls = nullptr; }
+        HIP_TRY(hipMalloc((void **)&h->wcls, wbytes));
+        h->device_bytes += (long long)wbytes;
+    }
+    if (!h->bcode) {
+        HIP_TRY(hipMalloc((void **)&h->bcode, cbytes));
+        HIP_TRY(hipMemsetAsync(h->bcode, 0, cbytes, h->s_compute));
+        h->device_bytes += (long long)cbytes;
+    }
+    if (!h->d_nbad) HIP_TRY(hipMalloc((void **)&h->d_nbad, sizeof(unsigned int)));
+    h->n_win = nwin;
+    const long nt = (long)(g.nxl + 2) * nwin;
+    hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->wcls, g, nwin);
+    hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->bcode, g);
+    HIP_TRY(hipGetLastError());
+    h->host_wcls.resize(wbytes);
+    HIP_TRY(hipMemcpyAsync(h->host_wcls.data(), h->wcls, wbytes, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    const FuseScan sc = scan_mask(h->host_mask.data(), h->g.nxl, h->g.ny);      // host_mask: [NY][nxl], local columns
+
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-    const long capacity = (long)prop.multiProcessorCount * 8;            // 4 SIMDs x 2 resident fused waves
+    const long slots = (long)prop.multiProcessorCount * 4 * 3;           // 3 resident plain waves per SIMD
+    const MarchRange r = march_range(g);
+    const long tiles = (long)(r.i_end - r.i_begin) * nwin;
+    // chunk length: about one resident round of units (all units of a launch run side by side, so a second,
+    // partly filled round costs a whole unit time); 24 columns keep the two re-read halo columns at 8 %
     int L = h->fuse_chunk;
-    if (L <= 0) L = auto_fuse_chunk(sc, capacity);
-    const FusePlan p = build_fuse_plan(sc, L);
-    h->fuse_chunk_used = L;
-    if (!p.usable) return WT_OK;
-    // measured (bench.py --fuse on 544/1056/2080-column lattices): with fewer units than resident
-    // wave slots the marching kernel cannot fill the chip and the single-step kernel is faster
-    if (!h->fuse_force && (long)p.units.size() < capacity) return WT_OK;
-    WT_TRY(upload_vec(&h->d_units, p.units, h));
-    WT_TRY(upload_vec(&h->d_t1, p.t1, h));
-    WT_TRY(upload_vec(&h->d_t2, p.t2, h));
-    h->n_units = (int)p.units.size(); h->n_t1 = (int)p.t1.size(); h->n_t2 = (int)p.t2.size(); h->n_win = p.nwin;
-    if (h->wtiles) { HIP_TRY(hipFree(h->wtiles)); h->wtiles = nullptr; }
-    HIP_TRY(hipMalloc((void **)&h->wtiles, (size_t)h->g.nxl * p.nwin));
-    WT_TRY(classify_tiles(h->mask, h->wtiles, h->g, p.nwin, h->s_compute, 256, FUSE_WIN_STRIDE));
-    HIP_TRY(hipStreamSynchronize(h->s_compute));
-    if (!h->f_tmp) {
-        const size_t lat_bytes = (size_t)9 * h->g.plane * h->esz;
-        HIP_TRY(hipMalloc(&h->f_tmp, lat_bytes));
-        // on the compute stream (a blocking-API hipMemset on the null stream is not ordered against
-        // this handle's non-blocking streams and could land after the first pass has written C)
-        HIP_TRY(hipMemsetAsync(h->f_tmp, 0, lat_bytes, h->s_compute));
-        HIP_TRY(hipStreamSynchronize(h->s_compute));
-        h->device_bytes += (long long)lat_bytes;
+    if (L <= 0) {
+        L = (int)((tiles + slots - 1) / slots);
+        if (L < 6) L = 6;
+        if (L > 48) L = 48;
     }
+    int Lb = h->fuse_chunk_body;
+    if (Lb <= 0) Lb = L < 16 ? (L > 4 ? L / 2 : L) : 8;
+    h->fuse_chunk_used = L;
+    // measured (bench.py --fuse on 544/1056/2080-column lattices): with much fewer units than resident wave slots
+    // the marching kernels cannot fill the chip and the single-step kernel is faster
+    if (!h->fuse_force && tiles / L < slots / 2) return WT_OK;
+    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, L, h->fuse_split ? Lb : (L > MARCH_MAX_BODY_CHUNK ? MARCH_MAX_BODY_CHUNK : L),
+                                          h->fuse_split != 0, 1.0);
+    const size_t total = pl.plain.size() + pl.body.size();
+    if (total == 0) return WT_OK;
+    if (total > h->units_cap) {
+        if (h->d_units) { HIP_TRY(hipFree(h->d_units)); h->d_units = nullptr; h->units_cap = 0; }
+        const size_t cap = total + total / 4 + 64;
+        HIP_TRY(hipMalloc((void **)&h->d_units, cap * sizeof(MarchUnit)));
+        h->units_cap = cap;
+    }
+    // chunk-major order: the windows of one chunk are neighbours in the list (adjacent waves read adjacent kilobytes)
+    std::vector<MarchUnit> all(pl.plain);
+    auto cmp = [](const MarchUnit &x, const MarchUnit &y) { return x.ia != y.ia ? x.ia < y.ia : x.w < y.w; };
+    std::stable_sort(all.begin(), all.end(), cmp);
+    std::vector<MarchUnit> body(pl.body);
+    std::stable_sort(body.begin(), body.end(), cmp);
+    all.insert(all.end(), body.begin(), body.end());
+    HIP_TRY(hipMemcpyAsync(h->d_units, all.data(), total * sizeof(MarchUnit), hipMemcpyHostToDevice, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    h->n_plain = (int)pl.plain.size();
+    h->n_body = (int)pl.body.size();
+    for (const MarchUnit &u : pl.body) h->body_cols += u.ib - u.ia;
     h->fuse_ready = true;
     return WT_OK;
 }
@@ -346,7 +387,7 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
     HIP_TRY(hipSetDevice(h->device));
     if (strcmp(name, "fuse_steps") == 0) {
         if (value != 0.0 && !fuse_eligible(h))
-            return fail(WT_ERR_STATE, "fuse_steps needs an fp32 handle with NY %% 4 == 0 and at least 8 local columns");
+            return fail(WT_ERR_STATE, "fuse_steps needs an fp32 handle with NY %% 4 == 0, at least 8 local columns and a lattice below 4 GiB");
         h->fuse = value != 0.0;
         h->fuse_force = value >= 2.0;
         return rebuild_fuse_plan(h);
@@ -356,6 +397,19 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->fuse_chunk = (int)value;
         return rebuild_fuse_plan(h);
     }
+    if (strcmp(name, "fuse_chunk_body") == 0) {
+        if (!(value >= 0.0 && value <= 4096.0)) return fail(WT_ERR_ARG, "fuse_chunk_body out of range (0 = automatic)");
+        h->fuse_chunk_body = (int)value;
+        return rebuild_fuse_plan(h);
+    }
+    if (strcmp(name, "fuse_split") == 0) {
+        h->fuse_split = value != 0.0 ? 1 : 0;
+        return rebuild_fuse_plan(h);
+    }
+    if (strcmp(name, "fast_div") == 0) {
+        h->fast_div = value != 0.0;
+        return WT_OK;
+    }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
 
@@ -363,11 +417,16 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
 {
     WT_TRY(check_handle(h));
     if (!name || !value) return fail(WT_ERR_ARG, "null argument");
-    if (strcmp(name, "fuse_steps") == 0) { *value = h->fuse ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "fuse_steps") == 0) { *value = h->fuse ? (h->fuse_force ? 2.0 : 1.0) : 0.0; return WT_OK; }
     if (strcmp(name, "fuse_active") == 0) { *value = h->fuse_ready ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_ready ? h->fuse_chunk_used : h->fuse_chunk; return WT_OK; }
-    if (strcmp(name, "fuse_units") == 0) { *value = h->n_units; return WT_OK; }
-    if (strcmp(name, "fuse_tiles_single") == 0) { *value = h->n_t2; return WT_OK; }
+    if (strcmp(name, "fuse_chunk_body") == 0) { *value = h->fuse_chunk_body; return WT_OK; }
+    if (strcmp(name, "fuse_split") == 0) { *value = h->fuse_split; return WT_OK; }
+    if (strcmp(name, "fuse_units") == 0) { *value = h->n_plain + h->n_body; return WT_OK; }
+    if (strcmp(name, "fuse_units_body") == 0) { *value = h->n_body; return WT_OK; }
+    if (strcmp(name, "fuse_tiles_single") == 0) { *value = h->body_cols; return WT_OK; }   // window-tiles marched by the BODY kernel
+    if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
 
@@ -415,13 +474,7 @@ extern "C" int wt_set_mask(wt_handle *h, const uint8_t *mask)
     WT_TRY(classify_tiles(h->mask, h->tiles, g, h->tiles_per_col, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     h->mask_set = true;
-    if (fuse_eligible(h)) {
-        // keep the LOCAL columns [gi0, gi0+nxl) of the mask (all inside the tunnel) for the fusion plan
-        h->host_mask.resize((size_t)g.nxl * g.ny);
-        for (int y = 0; y < g.ny; y++)
-            memcpy(h->host_mask.data() + (size_t)y * g.nxl, mask + (size_t)y * g.nx_g + g.gi0, (size_t)g.nxl);
-        WT_TRY(rebuild_fuse_plan(h));
-    }
+    WT_TRY(rebuild_fuse_plan(h));
     return WT_OK;
 }
 
@@ -587,45 +640,78 @@ static int step_once(wt_handle *h, double tau, double u0, bool emit)
     return step_compute(h, tau, u0, emit, refresh);
 }
 
-// Two steps in one pass over the lattice (step_fused.hpp).  A = f[cur] (time t), B = f[1-cur]
-// (receives time t+2), C = f_tmp (time t+1 on the tiles of the non-fusable zone only).
+// Is the three-operation division by tau exact for this tau?  Exhaustive check over all 2^23 significands on the
+// device (d2q9.hpp), once per tau; the answer selects the kernel instantiation.
+static int fastdiv_for(wt_handle *h, float tau, bool *use)
+{
+    *use = false;
+    if (!h->fast_div) return WT_OK;
+    if (!h->fd_checked || h->fd_tau != tau) {
+        const float rtau = 1.0f / tau;
+        HIP_TRY(hipMemsetAsync(h->d_nbad, 0, sizeof(unsigned int), h->s_compute));
+        hipLaunchKernelGGL(k_verify_fastdiv, dim3(1024), dim3(256), 0, h->s_compute, tau, rtau, h->d_nbad);
+        HIP_TRY(hipGetLastError());
+        unsigned int nbad = 1;
+        HIP_TRY(hipMemcpyAsync(&nbad, h->d_nbad, sizeof(nbad), hipMemcpyDeviceToHost, h->s_compute));
+        HIP_TRY(hipStreamSynchronize(h->s_compute));
+        h->fd_tau = tau;
+        h->fd_ok = (nbad == 0) && std::isfinite(rtau) && tau >= 0x1p-20f && tau <= 0x1p20f;
+        h->fd_checked = true;
+    }
+    *use = h->fd_ok;
+    return WT_OK;
+}
+
+template <bool BODY, bool EMIT, int FD>
+static void launch_march(const MarchParams &p, hipStream_t st)
+{
+    if (p.nunits <= 0) return;
+    hipLaunchKernelGGL((k_march<BODY, EMIT, FD, 2>), dim3((unsigned)((p.nunits + 3) / 4)), dim3(256), 0, st, p);
+}
+
+template <bool BODY>
+static void launch_march_any(const MarchParams &p, bool emit, bool fd, hipStream_t st)
+{
+    if (emit) { if (fd) launch_march<BODY, true, 1>(p, st); else launch_march<BODY, true, 0>(p, st); }
+    else { if (fd) launch_march<BODY, false, 1>(p, st); else launch_march<BODY, false, 0>(p, st); }
+}
+
+// Two steps in one pass over the lattice (step_march.hpp).  A = f[cur] (time t), B = f[1-cur] (receives time t+2).
+// The body units (BODY kernel) run on the second stream beside the plain units: both only read A and write
+// disjoint sites of B.
 static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
 {
     const Geom &g = h->g;
-    const float *A = fptr<float>(h, h->cur);
-    float *B = fptr<float>(h, 1 - h->cur);
-    float *C = reinterpret_cast<float *>(h->f_tmp);
-    float *macro = reinterpret_cast<float *>(h->macro);
-    const int rev = (int)((h->steps_done >> 1) & 1);
-    const float t = (float)tau, U = (float)u0;
-    // The two single-step passes over the body zone (small launches) run on the second stream,
-    // concurrently with the fused kernel: all three only read A; B is written on disjoint (or
-    // identically valued) sites; C belongs to the passes alone.
-    hipStream_t st = h->s_compute, sz = h->s_comm;
-    const bool zone = h->n_t1 > 0 || h->n_t2 > 0;
-    if (zone) {
+    bool fd = false;
+    WT_TRY(fastdiv_for(h, (float)tau, &fd));
+    MarchParams p;
+    p.fs = fptr<float>(h, h->cur);
+    p.fd = fptr<float>(h, 1 - h->cur);
+    p.macro = reinterpret_cast<float *>(h->macro);
+    p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls;
+    p.g = g;
+    p.lat_bytes = (unsigned)((size_t)9 * g.plane * 4);
+    p.fdv.tau = (float)tau; p.fdv.rtau = 1.0f / (float)tau;
+    p.U0 = (float)u0;
+    p.rev = (int)((h->steps_done >> 1) & 1);
+    hipStream_t st = h->s_compute, sb = h->s_comm;
+    const bool two = h->n_plain > 0 && h->n_body > 0;
+    if (two) {
         HIP_TRY(hipEventRecord(h->ev_state, st));
-        HIP_TRY(hipStreamWaitEvent(sz, h->ev_state, 0));
-        if (h->n_t1)
-            hipLaunchKernelGGL((k_step_list<float, false, WT_LOADMODE, 1>), dim3((h->n_t1 + 3) / 4), dim3(256), 0, sz, A, C, macro, h->mask,
-                               h->wtiles, h->n_win, g, (const int *)h->d_t1, h->n_t1, t, U, rev);
-        if (h->n_t2) {
-            if (emit)
-                hipLaunchKernelGGL((k_step_list<float, true, WT_LOADMODE, 2>), dim3((h->n_t2 + 3) / 4), dim3(256), 0, sz, (const float *)C, B,
-                                   macro, h->mask, h->wtiles, h->n_win, g, (const int *)h->d_t2, h->n_t2, t, U, rev);
-            else
-                hipLaunchKernelGGL((k_step_list<float, false, WT_LOADMODE, 2>), dim3((h->n_t2 + 3) / 4), dim3(256), 0, sz, (const float *)C, B,
-                                   macro, h->mask, h->wtiles, h->n_win, g, (const int *)h->d_t2, h->n_t2, t, U, rev);
-        }
-        HIP_TRY(hipEventRecord(h->ev_halo, sz));
+        HIP_TRY(hipStreamWaitEvent(sb, h->ev_state, 0));
     }
-    if (emit)
-        hipLaunchKernelGGL((k_step2<true>), dim3((h->n_units + 3) / 4), dim3(256), 0, st, A, B, macro, (const FuseUnit *)h->d_units,
-                           h->n_units, g, t, U, rev);
-    else
-        hipLaunchKernelGGL((k_step2<false>), dim3((h->n_units + 3) / 4), dim3(256), 0, st, A, B, macro, (const FuseUnit *)h->d_units,
-                           h->n_units, g, t, U, rev);
-    if (zone) HIP_TRY(hipStreamWaitEvent(st, h->ev_halo, 0));
+    if (h->n_body > 0) {
+        p.units = h->d_units + h->n_plain; p.nunits = h->n_body;
+        launch_march_any<true>(p, emit, fd, two ? sb : st);
+    }
+    if (h->n_plain > 0) {
+        p.units = h->d_units; p.nunits = h->n_plain;
+        launch_march_any<false>(p, emit, fd, st);
+    }
+    if (two) {
+        HIP_TRY(hipEventRecord(h->ev_halo, sb));
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_halo, 0));
+    }
     HIP_TRY(hipGetLastError());
     h->cur = 1 - h->cur;
     h->steps_done += 2;

@@ -1,7 +1,7 @@
-"""GPU: the opt-in two-steps-per-launch mode (csrc/step_fused.hpp) must be bit-identical to the
-ordinary single-step path and to the oracle: fused units (register-resident step 1 -> step 2),
-the single-step passes through the third lattice for the body zone, odd/even step counts, macro
-emission, mask changes, chunk sizes."""
+"""GPU: the two-steps-per-launch mode (csrc/step_march.hpp) must be bit-identical to the ordinary
+single-step path and to the oracle: plain units (register-resident step 1 -> step 2), body units
+(window-tile classes, bounce codes, inlet / outlet columns inside the march), odd/even step counts,
+macro emission, mask changes, chunk sizes, the proved fast division by tau and its IEEE fallback."""
 import numpy as np
 import pytest
 
@@ -86,12 +86,13 @@ def test_fused_toggle_midrun_and_4096(pkg):
         b.set_option("fuse_steps", 2)            # option set after the mask: the plan is rebuilt from the kept copy
         assert b.get_option("fuse_active") == 1.0
         b.step(4, 0.58, 0.06)
+        body_tiles = b.get_option("fuse_tiles_single")       # window-tiles marched by the BODY kernel
+        assert 0 < body_tiles < 0.15 * nx * (ny // 252 + 1)
+        assert b.get_option("fuse_units_body") > 0 and b.get_option("fast_div_active") == 1.0
         b.set_option("fuse_steps", 0)
         b.step(2, 0.58, 0.06)
         assert bits_equal(a.read_f(), b.read_f())
         assert all(bits_equal(x, y) for x, y in zip(a.read_macro(), b.read_macro()))
-        single = b.get_option("fuse_tiles_single")
-        assert 0 < single < 0.35 * nx * (ny // 256)
 
 
 def test_fused_not_available(pkg):

@@ -1,0 +1,325 @@
+// kmarch.hip — developer experiment for csrc/step_march.hpp (two steps per launch, body included):
+// bit-equality with two production k_step launches on lattices WITH a body / solids on every edge,
+// timing of the variants (fast division, waves per SIMD, chunk length), exhaustive fast-division proof.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/kmarch tools/kmarch.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+#include "../airfoil-cfd-tool_amd/csrc/kernels.hpp"
+#include "../airfoil-cfd-tool_amd/csrc/step_fast.hpp"
+#include "../airfoil-cfd-tool_amd/csrc/step_march.hpp"
+
+using namespace wt;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Lattice {
+    int nx, ny; Geom g; int tpc, nwin; size_t lat;
+    float *f0, *f1, *f2, *f3, *macro, *macro2; uint8_t *mask, *tiles, *bcode, *wcls;
+    std::vector<uint8_t> hmask;    // device layout (nx+2) x pitch
+    std::vector<uint8_t> hwcls;
+};
+
+// memory-pattern ceiling: the loads and stores of the plain march, no arithmetic.
+// MODE 0: exactly the march (252-row window stride, +-1 shifted loads, partial stores at the seams)
+// MODE 1: as 0 but full 16-B stores from all lanes
+// MODE 2: 256-row window stride, all loads and stores aligned (natural layout)
+// MODE 3: as 2 but a window-major ("tiled") address map: a wave's stream is sequential in memory
+// MODE 4: as 0/1 but aligned loads only (shifts would be done in registers)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
+{
+    const Geom &g = p.g;
+    const int lane = threadIdx.x & 63;
+    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= p.nunits) return;
+    if (p.rev) u = p.nunits - 1 - u;
+    const MarchUnit un = p.units[u];
+    const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
+    const int w = __builtin_amdgcn_readfirstlane(un.w);
+    if ((MODE == 2 || MODE == 3) && w >= g.ny / 256) return;
+    const int row0 = (MODE == 2 || MODE == 3) ? w * 256 : w * MARCH_STRIDE;
+    const int j0 = row0 + lane * 4;
+    const bool first_win = (w == 0);
+    MarchAddr a;
+    a.rs = march_rsrc(p.fs, p.lat_bytes); a.rd = march_rsrc(p.fd, p.lat_bytes);
+    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
+    a.voff = (MODE == 3) ? (unsigned)lane * 16u : (unsigned)j0 * 4u;
+    a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
+    auto off = [&](int k, int col) -> unsigned {
+        if (MODE == 3) return (unsigned)k * a.P4 + ((unsigned)w * (unsigned)(g.nxl + 2) + (unsigned)(col + 1)) * 1024u;
+        return lat_off(a, k, col, 0);
+    };
+    auto load9 = [&](int col, V4 (&x)[9]) {
+        if (MODE >= 2) {
+            x[0] = bload(a.rs, a.voff, off(0, col)); x[1] = bload(a.rs, a.voff, off(1, col - 1)); x[3] = bload(a.rs, a.voff, off(3, col + 1));
+            x[2] = bload(a.rs, a.voff, off(2, col)); x[5] = bload(a.rs, a.voff, off(5, col - 1)); x[6] = bload(a.rs, a.voff, off(6, col + 1));
+            x[4] = bload(a.rs, a.voff, off(4, col)); x[7] = bload(a.rs, a.voff, off(7, col + 1)); x[8] = bload(a.rs, a.voff, off(8, col - 1));
+        } else march_load_stream(a, col, x);
+    };
+    V4 in[9], mac[3];
+    load9(ia - 1, in);
+    load9(ia, in);
+    load9(ia + 1, in);
+#pragma unroll 1
+    for (int c = ia; c < ib; c++) {
+        V4 nxt[9];
+        load9((c + 2 <= ib) ? c + 2 : c + 1, nxt);
+        if (MODE == 0) march_store<false>(a, g.ny, c, j0, lane, first_win, in, mac);
+        else {
+#pragma unroll
+            for (int k = 0; k < 9; k++) bstore(a.rd, a.voff, off(k, c), in[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) in[k] = nxt[k];
+    }
+}
+
+struct DevPlan { MarchUnit *plain = nullptr, *body = nullptr; int nplain = 0, nbody = 0; };
+static DevPlan upload_plan(const Lattice &L, int Lp, int Lb, int order = 0, bool split = true, double alpha = 1.0)
+{
+    MarchPlan pl = build_march_plan(L.hwcls.data(), L.g, Lp, Lb, split, alpha);
+    if (order == 1) {   // chunk-major: adjacent windows of one chunk are neighbours in the list
+        auto cmp = [](const MarchUnit &x, const MarchUnit &y) { return x.ia != y.ia ? x.ia < y.ia : x.w < y.w; };
+        std::stable_sort(pl.plain.begin(), pl.plain.end(), cmp); std::stable_sort(pl.body.begin(), pl.body.end(), cmp);
+    }
+    DevPlan d; d.nplain = (int)pl.plain.size(); d.nbody = (int)pl.body.size();
+    if (d.nplain) { CK(hipMalloc(&d.plain, sizeof(MarchUnit) * d.nplain)); CK(hipMemcpy(d.plain, pl.plain.data(), sizeof(MarchUnit) * d.nplain, hipMemcpyHostToDevice)); }
+    if (d.nbody) { CK(hipMalloc(&d.body, sizeof(MarchUnit) * d.nbody)); CK(hipMemcpy(d.body, pl.body.data(), sizeof(MarchUnit) * d.nbody, hipMemcpyHostToDevice)); }
+    return d;
+}
+static void free_plan(DevPlan &d) { if (d.plain) (void)hipFree(d.plain); if (d.body) (void)hipFree(d.body); }
+
+static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
+{
+    Lattice L; L.nx = nx; L.ny = ny;
+    Geom &g = L.g; g.nxl = nx; g.ny = ny; g.gi0 = 0; g.nx_g = nx; g.pitch = ((long)ny + 255) / 256 * 256;
+    g.plane = (((long)(nx + 2) * g.pitch * 4 + 4095) / 4096 * 4096 + 17408) / 4;
+    L.tpc = (int)(g.pitch / 256); L.nwin = march_nwin(ny);
+    L.lat = (size_t)9 * g.plane * 4;
+    CK(hipMalloc(&L.f0, L.lat)); CK(hipMalloc(&L.f1, L.lat)); CK(hipMalloc(&L.f2, L.lat)); CK(hipMalloc(&L.f3, L.lat));
+    CK(hipMalloc(&L.macro, (size_t)3 * nx * g.pitch * 4)); CK(hipMalloc(&L.macro2, (size_t)3 * nx * g.pitch * 4));
+    CK(hipMalloc(&L.mask, (size_t)(nx + 2) * g.pitch)); CK(hipMalloc(&L.tiles, (size_t)nx * L.tpc));
+    CK(hipMalloc(&L.bcode, (size_t)(nx + 2) * g.pitch)); CK(hipMalloc(&L.wcls, (size_t)(nx + 2) * L.nwin));
+    L.hmask.assign((size_t)(nx + 2) * g.pitch, 0);
+    auto set = [&](int x, int j) { if (x >= 0 && x < nx && j >= 0 && j < ny) L.hmask[(size_t)(x + 1) * g.pitch + j] = 1; };
+    if (body >= 1) {   // rotated ellipse (an "airfoil") + a thin plate
+        const double cx = nx * 0.4, cy = ny * 0.5, a = nx * 0.25, b = ny * 0.03, th = -10.0 * M_PI / 180.0;
+        for (int x = 0; x < nx; x++) for (int j = 0; j < ny; j++) {
+            const double dx = x - cx, dy = j - cy;
+            const double u = dx * cos(th) + dy * sin(th), v = -dx * sin(th) + dy * cos(th);
+            if (u * u / (a * a) + v * v / (b * b) <= 1.0) set(x, j);
+        }
+        for (int x = nx * 3 / 4; x < nx * 3 / 4 + 2; x++) for (int j = ny / 3; j < ny / 3 + ny / 10; j++) set(x, j);
+    }
+    if (body >= 2) {   // solids on every edge, isolated cells, window seams
+        for (int j = ny / 5; j < ny / 5 + 9; j++) { set(0, j); set(1, j); set(nx - 1, j); set(nx - 2, j); }
+        for (int x = nx / 6; x < nx / 6 + 7; x++) { set(x, 0); set(x, 1); set(x, ny - 1); set(x, ny - 2); }
+        for (int w = 1; w < L.nwin; w++) for (int d = -3; d <= 5; d++) set(nx / 2 + w * 3, w * 252 + d);
+        unsigned long long s = 12345;
+        for (int t = 0; t < (nx * ny) / 400; t++) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; const int x = (int)((s >> 33) % nx); s = s * 6364136223846793005ULL + 1442695040888963407ULL; const int j = (int)((s >> 33) % ny); set(x, j); }
+        set(0, 0); set(nx - 1, ny - 1); set(nx - 1, 0); set(0, ny - 1);
+    }
+    CK(hipMemcpy(L.mask, L.hmask.data(), L.hmask.size(), hipMemcpyHostToDevice));
+    classify_tiles(L.mask, L.tiles, g, L.tpc, st);
+    const long nt = (long)(nx + 2) * L.nwin;
+    hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, L.mask, L.wcls, g, L.nwin);
+    CK(hipMemsetAsync(L.bcode, 0, (size_t)(nx + 2) * g.pitch, st));
+    hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, st, L.mask, L.bcode, g);
+    CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+    L.hwcls.resize((size_t)(nx + 2) * L.nwin);
+    CK(hipMemcpy(L.hwcls.data(), L.wcls, L.hwcls.size(), hipMemcpyDeviceToHost));
+    {   // non-trivial initial state: pseudo-random perturbation of the equilibrium
+        std::vector<float> h((size_t)9 * g.plane);
+        const double u0 = 0.06;
+        unsigned long long x = 88172645463325252ULL;
+        for (int k = 0; k < 9; k++) {
+            const double wgt = k == 0 ? 4.0 / 9 : (k <= 4 ? 1.0 / 9 : 1.0 / 36); const double eu = ex_of(k) * u0;
+            const float base = (float)(wgt * (1 + 3 * eu + 4.5 * eu * eu - 1.5 * u0 * u0));
+            for (long t = 0; t < g.plane; t++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[(size_t)k * g.plane + t] = base * (1.0f + 0.02f * ((x >> 40) / 16777216.0f - 0.5f)); }
+        }
+        CK(hipMemcpy(L.f0, h.data(), L.lat, hipMemcpyHostToDevice));
+    }
+    return L;
+}
+static void free_lattice(Lattice &L)
+{
+    (void)hipFree(L.f0); (void)hipFree(L.f1); (void)hipFree(L.f2); (void)hipFree(L.f3); (void)hipFree(L.macro); (void)hipFree(L.macro2); (void)hipFree(L.mask); (void)hipFree(L.tiles); (void)hipFree(L.bcode); (void)hipFree(L.wcls);
+}
+
+static MarchParams march_params(const Lattice &L, const float *a, float *b, float *macro, const MarchUnit *units, int nunits, float tau, float rtau, float U0, int rev)
+{
+    MarchParams p;
+    p.fs = a; p.fd = b; p.macro = macro; p.mask = L.mask; p.bcode = L.bcode; p.wcls = L.wcls; p.g = L.g;
+    p.units = units; p.nunits = nunits; p.lat_bytes = (unsigned)L.lat;
+    p.fdv.tau = tau; p.fdv.rtau = rtau; p.U0 = U0; p.rev = rev;
+    return p;
+}
+// one pass = the plain units on `st`, the body units on `sb` (sb == st: one after the other)
+template <bool EMIT, int FD, int WP, int WB>
+static void march_pass(const Lattice &L, const DevPlan &d, const float *a, float *b, float *macro, float tau, float U0, int rev, hipStream_t st, hipStream_t sb, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const float rtau = 1.0f / tau;
+    if (sb != st) { CK(hipEventRecord(ev0, st)); CK(hipStreamWaitEvent(sb, ev0, 0)); }
+    if (d.nbody) hipLaunchKernelGGL((k_march<true, EMIT, FD, WB>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), 0, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
+    if (d.nplain) hipLaunchKernelGGL((k_march<false, EMIT, FD, WP>), dim3((unsigned)((d.nplain + 3) / 4)), dim3(256), 0, st, march_params(L, a, b, macro, d.plain, d.nplain, tau, rtau, U0, rev));
+    if (sb != st) { CK(hipEventRecord(ev1, sb)); CK(hipStreamWaitEvent(st, ev1, 0)); }
+}
+
+static long compare(const Lattice &L, const float *x, const float *y, size_t planes, long plane_stride, const char *what)
+{
+    std::vector<float> a((size_t)plane_stride), b((size_t)plane_stride);
+    long bad = 0;
+    for (size_t k = 0; k < planes; k++) {
+        CK(hipMemcpy(a.data(), x + k * plane_stride, plane_stride * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(b.data(), y + k * plane_stride, plane_stride * 4, hipMemcpyDeviceToHost));
+        const long off = (planes == 9) ? L.g.pitch : 0;     // lattices have a pad column in front, macro planes do not
+        for (int i = 0; i < L.nx; i++) for (int j = 0; j < L.ny; j++) {
+            const size_t o = (size_t)off + (size_t)i * L.g.pitch + j;
+            if (memcmp(&a[o], &b[o], 4) != 0) { if (bad < 6) printf("  %s mismatch k=%zu i=%d j=%d: %.9g vs %.9g\n", what, k, i, j, a[o], b[o]); bad++; }
+        }
+    }
+    return bad;
+}
+
+static void check_case(int nx, int ny, int body, int Lp, int Lb, float tau, hipStream_t st, hipStream_t sb, hipEvent_t ev0, hipEvent_t ev1)
+{
+    Lattice L = make_lattice(nx, ny, body, st);
+    const float U0 = 0.06f;
+    step_columns<float, 3>(L.f0, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st);
+    step_columns<float, 3>(L.f1, L.f2, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, true, 1, st);
+    CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+    DevPlan d = upload_plan(L, Lp, Lb);
+    for (int variant = 0; variant < 2; variant++) {
+        CK(hipMemset(L.f3, 0xff, L.lat)); CK(hipMemset(L.macro2, 0xff, (size_t)3 * nx * L.g.pitch * 4));
+        if (variant == 0) march_pass<true, 0, 2, 2>(L, d, L.f0, L.f3, L.macro2, tau, U0, 0, st, st, ev0, ev1);
+        else march_pass<true, 1, 2, 2>(L, d, L.f0, L.f3, L.macro2, tau, U0, 1, st, sb, ev0, ev1);
+        CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(sb)); CK(hipGetLastError());
+        const long bad = compare(L, L.f2, L.f3, 9, L.g.plane, "f");
+        const long badm = compare(L, L.macro, L.macro2, 3, (long)nx * L.g.pitch, "macro");
+        printf("check %dx%d body=%d Lp=%d Lb=%d tau=%g %s: plain %d body %d units; %ld f values, %ld macro values differ\n", nx, ny, body, Lp, Lb, tau, variant ? "fastdiv rev 2-stream" : "ieee", d.nplain, d.nbody, bad, badm);
+    }
+    free_plan(d);
+    free_lattice(L);
+}
+
+int main(int argc, char **argv)
+{
+    const int nx = argc > 1 ? atoi(argv[1]) : 4096, ny = argc > 2 ? atoi(argv[2]) : 4096, rounds = argc > 3 ? atoi(argv[3]) : 8;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    // ---- fast-division proof for a set of relaxation times
+    {
+        unsigned int *nbad; CK(hipMalloc(&nbad, 4));
+        std::vector<float> taus = {0.58f, 0.5004007f, 0.51f, 0.55f, 0.6f, 0.75f, 1.0f, 1.5f, 0.9999999f, 1.9999999f, 0.50000006f};
+        unsigned long long s = 99;
+        for (int t = 0; t < 400; t++) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; taus.push_back(0.5f + 1.5f * (float)((s >> 40) / 16777216.0)); }
+        int nfail = 0;
+        for (float tau : taus) {
+            CK(hipMemset(nbad, 0, 4));
+            hipLaunchKernelGGL(k_verify_fastdiv, dim3(1024), dim3(256), 0, st, tau, 1.0f / tau, nbad);
+            unsigned int h; CK(hipMemcpyAsync(&h, nbad, 4, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st));
+            if (h) { nfail++; if (nfail < 10) printf("fastdiv: tau=%.9g fails for %u significands\n", tau, h); }
+        }
+        printf("fastdiv proof: %d of %zu relaxation times fail (tau=0.58 and 0.5004007 are the first two)\n", nfail, taus.size());
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(k_verify_fastdiv, dim3(1024), dim3(256), 0, st, 0.58f, 1.0f / 0.58f, nbad);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("fastdiv proof kernel: %.1f us\n", ms * 1e3);
+    }
+    hipStream_t sb; CK(hipStreamCreate(&sb));
+    hipEvent_t ev0, ev1; CK(hipEventCreateWithFlags(&ev0, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
+    // ---- bit-equality on small lattices with nasty masks
+    check_case(512, 512, 2, 7, 5, 0.58f, st, sb, ev0, ev1);
+    check_case(264, 508, 2, 61, 60, 0.58f, st, sb, ev0, ev1);
+    check_case(96, 256, 2, 3, 2, 0.5004f, st, sb, ev0, ev1);
+    check_case(1024, 512, 1, 16, 8, 0.58f, st, sb, ev0, ev1);
+    check_case(64, 1000, 2, 5, 1, 0.9f, st, sb, ev0, ev1);
+    check_case(640, 768, 0, 24, 8, 0.58f, st, sb, ev0, ev1);
+    // ---- the bench lattice
+    Lattice L = make_lattice(nx, ny, 1, st);
+    Lattice L0 = make_lattice(nx, ny, 0, st);
+    const float tau = 0.58f, U0 = 0.06f;
+    {
+        step_columns<float, 3>(L.f0, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st);
+        step_columns<float, 3>(L.f1, L.f2, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st);
+        CK(hipMemset(L.f3, 0xff, L.lat));
+        DevPlan d = upload_plan(L, 24, 8);
+        march_pass<false, 1, 2, 2>(L, d, L.f0, L.f3, L.macro2, tau, U0, 0, st, sb, ev0, ev1);
+        CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+        printf("check %dx%d body Lp=24 Lb=8 fastdiv: plain %d body %d units; %ld f values differ\n", nx, ny, d.nplain, d.nbody, compare(L, L.f2, L.f3, 9, L.g.plane, "f"));
+        free_plan(d);
+        DevPlan du = upload_plan(L, 24, 24, 1, false);
+        CK(hipMemset(L.f3, 0xff, L.lat));
+        march_pass<false, 1, 2, 2>(L, du, L.f0, L.f3, L.macro2, tau, U0, 1, st, st, ev0, ev1);
+        CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+        printf("check %dx%d body unified L=24 fastdiv: %d units; %ld f values differ\n", nx, ny, du.nbody, compare(L, L.f2, L.f3, 9, L.g.plane, "f"));
+        free_plan(du);
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    struct Var { std::string name; std::function<void(const float *, float *, int)> fn; std::vector<float> ms; int steps; };
+    std::vector<Var> vs;
+    std::vector<DevPlan> plans; plans.reserve(256);
+    vs.push_back({"k_step x2 (production)", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(L.f1, b, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
+    for (int order : {1}) for (int Lp : {24}) {
+        plans.push_back(upload_plan(L0, Lp, 8, order)); DevPlan *d0 = &plans.back();
+        const std::string tag = " ord=" + std::to_string(order) + " Lp=" + std::to_string(Lp) + " (" + std::to_string(d0->nplain) + ")";
+        vs.push_back({"nobody ieee" + tag, [&, d0](const float *a, float *b, int r) { march_pass<false, 0, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
+        vs.push_back({"nobody fdiv" + tag, [&, d0](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
+        vs.push_back({"nobody BODYkernel w3 ieee" + tag, [&, d0](const float *a, float *b, int r) { hipLaunchKernelGGL((k_march<true, false, 0, 3>), dim3((unsigned)((d0->nplain + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, d0->plain, d0->nplain, tau, 1.0f / tau, U0, r)); }, {}, 2});
+        vs.push_back({"nobody BODYkernel w2 ieee" + tag, [&, d0](const float *a, float *b, int r) { hipLaunchKernelGGL((k_march<true, false, 0, 2>), dim3((unsigned)((d0->nplain + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, d0->plain, d0->nplain, tau, 1.0f / tau, U0, r)); }, {}, 2});
+#define COPYV(M, label) vs.push_back({label + tag, [&, d0](const float *a, float *b, int r) { hipLaunchKernelGGL((k_march_copy<M>), dim3((unsigned)((d0->nplain + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, d0->plain, d0->nplain, tau, 1.0f / tau, U0, r)); }, {}, 2})
+        COPYV(0, std::string("copy0 march pattern      "));
+        COPYV(1, std::string("copy1 full stores        "));
+        COPYV(4, std::string("copy4 aligned loads      "));
+        COPYV(2, std::string("copy2 256-stride aligned "));
+        COPYV(3, std::string("copy3 tiled sequential   "));
+    }
+    for (double alpha : {0.0, 0.5, 1.0, 2.0}) for (int Lu : {16, 24, 28}) {
+        plans.push_back(upload_plan(L, Lu, Lu, 1, false, alpha)); DevPlan *d1 = &plans.back();
+        char buf[64]; snprintf(buf, sizeof buf, " a=%.1f L=%d (%d)", alpha, Lu, d1->nbody);
+        const std::string tag = buf;
+        vs.push_back({"body unified ieee w2" + tag, [&, d1](const float *a, float *b, int r) { march_pass<false, 0, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
+        vs.push_back({"body unified fdiv w2" + tag, [&, d1](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
+    }
+    for (int order : {1}) for (int Lp : {16, 24}) for (int Lb : {4}) {
+        plans.push_back(upload_plan(L, Lp, Lb, order)); DevPlan *d1 = &plans.back();
+        const std::string tag = " ord=" + std::to_string(order) + " Lp=" + std::to_string(Lp) + " Lb=" + std::to_string(Lb) + " (" + std::to_string(d1->nplain) + "+" + std::to_string(d1->nbody) + ")";
+        vs.push_back({"body fdiv 2-stream" + tag, [&, d1](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, sb, ev0, ev1); }, {}, 2});
+    }
+    if (argc > 4 && std::string(argv[4]) == "prof") {
+        // one variant per kernel name, few launches: for rocprofv3 --pmc
+        DevPlan dp = upload_plan(L0, 24, 8, 1);
+        for (int q = 0; q < 6; q++) {
+            const float *a = (q & 1) ? L0.f3 : L0.f0; float *b = (q & 1) ? L0.f0 : L0.f3;
+            march_pass<false, 0, 2, 2>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
+            march_pass<false, 1, 2, 2>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
+            march_pass<false, 2, 2, 2>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
+            hipLaunchKernelGGL((k_march_copy<1>), dim3((unsigned)((dp.nplain + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, dp.plain, dp.nplain, tau, 1.0f / tau, U0, q & 1));
+            step_columns<float, 3>(a, b, L0.macro, L0.mask, L0.tiles, L0.tpc, L0.g, 0, nx, tau, U0, false, q & 1, st);
+        }
+        CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+        return 0;
+    }
+    const int reps = 4;
+    for (int r = 0; r < rounds + 2; r++)
+        for (auto &v : vs) {
+            CK(hipEventRecord(e0, st));
+            for (int q = 0; q < reps; q++) { if (q & 1) v.fn(L.f3, L.f0, 1); else v.fn(L.f0, L.f3, 0); }
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) v.ms.push_back(ms / reps / v.steps);
+        }
+    printf("%-60s %12s %12s %10s\n", "variant", "us per STEP", "min", "GLUPS");
+    for (auto &v : vs) {
+        std::sort(v.ms.begin(), v.ms.end());
+        const double med = v.ms[v.ms.size() / 2];
+        printf("%-60s %12.1f %12.1f %10.1f\n", v.name.c_str(), med * 1e3, v.ms[0] * 1e3, (double)nx * ny / (med * 1e-3) / 1e9);
+    }
+    return 0;
+}
