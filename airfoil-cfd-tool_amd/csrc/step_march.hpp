@@ -4,9 +4,16 @@
 // Per iteration it (1) requests the 9 streamed input vectors of column c+2 (software prefetch),
 // (2) runs step 1 (STEP_FS main(), html:283-360) for column c+1 on the vectors requested one
 // iteration earlier, (3) runs step 2 for column c from the step-1 populations of columns c-1, c, c+1,
-// which never leave the register file (the +-1 shifts along j are lane shuffles, so the first and last
-// two rows of a window are not produced and windows advance by 252 rows), (4) stores 9 vectors.
+// which never leave the register file (the +-1 shifts along j are lane shuffles), (4) stores 9 vectors.
 // HBM words per TWO site updates: 9 (L+2)/L + 9 instead of 18 + 18.
+//
+// Windows are 256 rows tall and 256 rows apart, so every access of a wave is one whole, 1-KiB-aligned
+// kilobyte (measured with the arithmetic removed: a 252-row window pitch — overlapping windows that
+// recompute their seam rows — costs 13-20 % of the pass time in line straddles and partial-line stores).
+// What step 2 of a window's first and last row needs from the rows just outside the window — the step-1
+// populations 2,5,6 of the row below and 4,7,8 of the row above — comes from a small table H that
+// k_halo_rows fills before each pass (two rows per window seam, per-site code with every branch of
+// STEP_FS); a wave fetches its six values per column with one dword load, one iteration ahead.
 //
 // Two instantiations share the code:
 //   * BODY = false — "plain" units: no solid site inside the unit's input footprint, no inlet / outlet
@@ -33,12 +40,12 @@
 
 namespace wt {
 
-static constexpr int MARCH_STRIDE = 252;         // rows a window advances by (256 loaded, 2 + 2 overlap)
+static constexpr int MARCH_WIN = 256;            // window height = window pitch
 static constexpr int MARCH_MAX_BODY_CHUNK = 60;  // class bytes of columns ia-1 .. ib+1 must fit one wave
 
 enum : uint8_t { WC_FAST = 0, WC_GENERAL = 1, WC_SOLID = 2 };
 
-static inline int march_nwin(int ny) { return (ny - 2 + MARCH_STRIDE - 1) / MARCH_STRIDE; }
+static inline int march_nwin(int ny) { return (ny + MARCH_WIN - 1) / MARCH_WIN; }
 
 // ------------------------------------------------------------------------------------------------
 // once per mask upload
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256) void k_classify_windows(const uint8_t *__restr
     const int w = (int)(tile / ld), x = (int)(tile % ld) - 1;
     uint8_t cls = WC_FAST;
     if (x >= 0 && x < g.nxl) {
-        const int j0 = w * MARCH_STRIDE;
+        const int j0 = w * MARCH_WIN;
         const uint8_t *m = mask + g.pitch;
         int nb = 0, own_all = 1;
         for (int jj = j0 - 1 + lane; jj <= j0 + 256; jj += 64) {
@@ -89,6 +96,58 @@ __global__ __launch_bounds__(256) void k_bounce_codes(const uint8_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// once per pass: the halo table
+// ------------------------------------------------------------------------------------------------
+// One lattice site, step 1 only, every branch of STEP_FS main() (html:283-360) in the reference's order —
+// the arithmetic of site_general (kernels.hpp) with the relaxation of collide_fd.
+template <int FD>
+__device__ __forceinline__ void site_step1(const float *__restrict__ s, const uint8_t *__restrict__ m, const Geom &g, int i, int j,
+                                           const FastDiv &fdv, float U0, float (&out)[9])
+{
+    const long c = (long)i * g.pitch + j;
+    const int gi = i + g.gi0;
+    if (m[c]) {                                                    // html:287-294 solid
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = s[opp_of(k) * g.plane + c];
+    } else if (gi == g.nx_g - 1) {                                 // html:301-312 outlet
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = s[k * g.plane + c - g.pitch];
+    } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
+        feq_all(1.0f, U0, 0.0f, out);
+    } else {                                                       // html:324-359 interior fluid
+        float fin[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
+            fin[k] = m[src] ? s[opp_of(k) * g.plane + c] : s[k * g.plane + src];
+        }
+        collide_fd<FD>(fin, fdv, out, rho, ux, uy);
+    }
+}
+
+// H[(b * (nxl+2) + x + 1) * 8 + ...], seam b = 1 .. nwin-1 lies between rows 256b-1 and 256b:
+//   [0..2] = step-1 populations 2,5,6 of row 256b-1 (they move up into window b),
+//   [4..6] = step-1 populations 4,7,8 of row 256b   (they move down into window b-1).
+template <int FD>
+__global__ __launch_bounds__(256) void k_halo_rows(const float *__restrict__ fs, const uint8_t *__restrict__ mask, float *__restrict__ halo,
+                                                   Geom g, int nwin, FastDiv fdv, float U0)
+{
+    const long total = (long)(nwin - 1) * 2 * g.nxl;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % g.nxl);
+    const int r = (int)(t / g.nxl);
+    const int side = r & 1, b = 1 + (r >> 1);
+    const int j = MARCH_WIN * b - 1 + side;
+    if (j >= g.ny) return;
+    float out[9];
+    site_step1<FD>(fs + g.pitch, mask + g.pitch, g, x, j, fdv, U0, out);
+    float *rec = halo + ((long)b * (g.nxl + 2) + x + 1) * 8;
+    if (side == 0) { rec[0] = out[2]; rec[1] = out[5]; rec[2] = out[6]; }
+    else { rec[4] = out[4]; rec[5] = out[7]; rec[6] = out[8]; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // units
 // ------------------------------------------------------------------------------------------------
 struct MarchUnit { int ia, ib, w, flags; };      // marched columns [ia, ib), window; flags bit 0: emit the outlet column ib with column ib-1
@@ -101,10 +160,12 @@ struct MarchParams {
     const uint8_t *mask;       // padded byte mask (column -1 first)
     const uint8_t *bcode;      // bounce codes, column 0 first
     const uint8_t *wcls;       // window-tile classes [nwin][nxl + 2]
+    const float *halo;         // H[nwin + 1][nxl + 2][8], see k_halo_rows
     const MarchUnit *units;
     int nunits;
     Geom g;
     unsigned lat_bytes;        // bytes of one lattice (9 planes) — below 4 GiB
+    int nwin_total;            // windows per column
     FastDiv fdv;
     float U0;
     int rev;
@@ -116,9 +177,10 @@ typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ V4 v4_splat(float x) { V4 r; r.v[0] = x; r.v[1] = x; r.v[2] = x; r.v[3] = x; return r; }
 
-// value at j-1 / j+1 taken from the neighbouring lane (window-edge rows get garbage: never stored)
-__device__ __forceinline__ V4 m_below(const V4 &r) { V4 o; o.v[0] = lane_up(r.v[3]); o.v[1] = r.v[0]; o.v[2] = r.v[1]; o.v[3] = r.v[2]; return o; }
-__device__ __forceinline__ V4 m_above(const V4 &r) { V4 o; o.v[0] = r.v[1]; o.v[1] = r.v[2]; o.v[2] = r.v[3]; o.v[3] = lane_down(r.v[0]); return o; }
+// value at j-1 / j+1 taken from the neighbouring lane
+// (lane 0 / lane 63 take the value of the row outside the window from the halo table: `edge`, wave-uniform)
+__device__ __forceinline__ V4 m_below(const V4 &r, int lane, float edge) { V4 o; const float n = lane_up(r.v[3]); o.v[0] = lane == 0 ? edge : n; o.v[1] = r.v[0]; o.v[2] = r.v[1]; o.v[3] = r.v[2]; return o; }
+__device__ __forceinline__ V4 m_above(const V4 &r, int lane, float edge) { V4 o; const float n = lane_down(r.v[0]); o.v[0] = r.v[1]; o.v[1] = r.v[2]; o.v[2] = r.v[3]; o.v[3] = lane == 63 ? edge : n; return o; }
 
 // buffer addressing: rsrc = whole lattice; voff = the lane's byte offset (j0 * 4, loop-invariant);
 // soff = scalar byte offset of (plane, column, row shift)
@@ -282,30 +344,17 @@ __device__ __forceinline__ void march_outlet_macro(const V4 (&q9)[9], V4 (&mac)[
     }
 }
 
-// store the window's output rows of column `col`: lane 0 keeps rows J0+2.. (unless first window), lane 63 rows ..J0+253
+// store the window's rows of column `col` (lanes beyond the last row hold nothing)
 template <bool EMIT>
-__device__ __forceinline__ void march_store(const MarchAddr &a, int ny, int col, int j0, int lane, bool first_win, const V4 (&out)[9], const V4 (&mac)[3])
+__device__ __forceinline__ void march_store(const MarchAddr &a, int ny, int col, int j0, const V4 (&out)[9], const V4 (&mac)[3])
 {
-    if (j0 + 3 >= ny) return;
-    const unsigned mo = (unsigned)col * a.pitch4;
-    if (lane == 0 && !first_win) {
+    if (j0 >= ny) return;
 #pragma unroll
-        for (int k = 0; k < 9; k++) bstore2(a.rd, a.voff, lat_off(a, k, col, 2), out[k].v[2], out[k].v[3]);
-        if (EMIT)
+    for (int k = 0; k < 9; k++) bstore(a.rd, a.voff, lat_off(a, k, col, 0), out[k]);
+    if (EMIT) {
+        const unsigned mo = (unsigned)col * a.pitch4;
 #pragma unroll
-            for (int q = 0; q < 3; q++) bstore2(a.rm, a.voff, (unsigned)q * a.mp4 + mo + 8u, mac[q].v[2], mac[q].v[3]);
-    } else if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) bstore2(a.rd, a.voff, lat_off(a, k, col, 0), out[k].v[0], out[k].v[1]);
-        if (EMIT)
-#pragma unroll
-            for (int q = 0; q < 3; q++) bstore2(a.rm, a.voff, (unsigned)q * a.mp4 + mo, mac[q].v[0], mac[q].v[1]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; k++) bstore(a.rd, a.voff, lat_off(a, k, col, 0), out[k]);
-        if (EMIT)
-#pragma unroll
-            for (int q = 0; q < 3; q++) bstore(a.rm, a.voff, (unsigned)q * a.mp4 + mo, mac[q]);
+        for (int q = 0; q < 3; q++) bstore(a.rm, a.voff, (unsigned)q * a.mp4 + mo, mac[q]);
     }
 }
 
@@ -361,16 +410,26 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
     const MarchUnit un = p.units[u];
     const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
     const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
-    const int row0 = w * MARCH_STRIDE;
+    const int row0 = w * MARCH_WIN;
     const int j0 = row0 + lane * 4;
-    const bool first_win = (w == 0);
-    const bool far_win = first_win || (row0 + 256 >= g.ny);      // the window holds row 0 or row NY-1
+    const bool far_win = (w == 0) || (row0 + MARCH_WIN >= g.ny);   // the window holds row 0 or row NY-1
     MarchAddr a;
     a.rs = march_rsrc(p.fs, p.lat_bytes);
     a.rd = march_rsrc(p.fd, p.lat_bytes);
     a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
-    a.voff = (unsigned)j0 * 4u;
+    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * 4u;          // lanes beyond the last row re-read the window's first rows (cached) and store nothing
     a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
+    // halo table: lanes 0..5 fetch, for step 2 of column c, {G2(c), G5(c-1), G6(c+1)} of the row below the window
+    // (seam w) and {G4(c), G7(c+1), G8(c-1)} of the row above it (seam w+1); record = 8 floats per (seam, column)
+    const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.halo, (unsigned)((unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 32u));
+    unsigned hoff;
+    {
+        const int hl = lane < 6 ? lane : 0;
+        const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
+        const int slot = hl < 3 ? hl : hl + 1;
+        const int seam = hl < 3 ? w : w + 1;
+        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 32 + slot * 4);
+    }
     float feq0[9];
     feq_all<float>(1.0f, p.U0, 0.0f, feq0);                       // far-field populations (html:314-322)
 
@@ -400,16 +459,21 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
     march_load_stream(a, ia, in);
     STEP1(ia, in, Gc);
     march_load_stream(a, ia + 1, in);
+    unsigned hv = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (unsigned)ia * 32u, 0);
 #pragma unroll 1
     for (int c = ia; c < ib; c++) {
         V4 nxt[9];
         march_load_stream(a, (c + 2 <= ib) ? c + 2 : c + 1, nxt);             // prefetch (last one: harmless re-load)
+        const unsigned hv_next = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (unsigned)(c + 1) * 32u, 0);
         STEP1(c + 1, in, G);                                                  // step 1 of column c+1
+        const float hb2 = __uint_as_float(__builtin_amdgcn_readlane(hv, 0)), hb5 = __uint_as_float(__builtin_amdgcn_readlane(hv, 1)),
+                    hb6 = __uint_as_float(__builtin_amdgcn_readlane(hv, 2)), ha4 = __uint_as_float(__builtin_amdgcn_readlane(hv, 3)),
+                    ha7 = __uint_as_float(__builtin_amdgcn_readlane(hv, 4)), ha8 = __uint_as_float(__builtin_amdgcn_readlane(hv, 5));
         // ---- step 2 of column c
         V4 fin[9], out[9];
         fin[0] = Gc[0]; fin[1] = G158m[0]; fin[3] = G[3];
-        fin[2] = m_below(Gc[2]); fin[5] = m_below(G158m[1]); fin[6] = m_below(G[6]);
-        fin[4] = m_above(Gc[4]); fin[8] = m_above(G158m[2]); fin[7] = m_above(G[7]);
+        fin[2] = m_below(Gc[2], lane, hb2); fin[5] = m_below(G158m[1], lane, hb5); fin[6] = m_below(G[6], lane, hb6);
+        fin[4] = m_above(Gc[4], lane, ha4); fin[8] = m_above(G158m[2], lane, ha8); fin[7] = m_above(G[7], lane, ha7);
         bool plain = true;
         if (BODY) {
             const int gi = c + g.gi0;
@@ -442,7 +506,7 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
             march_collide<FD, EMIT>(fin, p.fdv, out, mac);
             if (far_win) march_far_rows<EMIT>(j0, g.ny, p.U0, feq0, out, mac);
         }
-        march_store<EMIT>(a, g.ny, c, j0, lane, first_win, out, mac);
+        march_store<EMIT>(a, g.ny, c, j0, out, mac);
         if (BODY && __builtin_expect((uflags & MU_OUTLET_AFTER) && c + 1 == ib, 0)) {
             // outlet column NX-1 (html:301-312): its step-2 value is the step-1 state of column NX-2 (= Gc), its own
             // step-1 state (solid sites only) is G
@@ -453,11 +517,12 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
             for (int k = 0; k < 9; k++) out[k] = Gc[k];
             if (EMIT) march_outlet_macro(Gc, mac);
             if (__ballot(solid4 != 0) != 0ULL) march_solid<EMIT>(out, mac, solid4, ownp);
-            march_store<EMIT>(a, g.ny, c + 1, j0, lane, first_win, out, mac);
+            march_store<EMIT>(a, g.ny, c + 1, j0, out, mac);
         }
         G158m[0] = Gc[1]; G158m[1] = Gc[5]; G158m[2] = Gc[8];
 #pragma unroll
         for (int k = 0; k < 9; k++) { Gc[k] = G[k]; in[k] = nxt[k]; }
+        hv = hv_next;
     }
 #undef NONFAST
 #undef ALLSOLID

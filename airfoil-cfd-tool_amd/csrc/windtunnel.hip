@@ -95,11 +95,12 @@ struct wt_handle {
     bool fuse_force = false;             // fuse_steps = 2: also when the lattice is too small for it to pay
     int fuse_chunk = 0;                  // plain-unit cost limit; 0 = chosen from the lattice size
     int fuse_chunk_body = 0;             // body-unit cost limit; 0 = automatic
-    int fuse_split = 1;                  // 1: plain units through the lean kernel, the rest through the BODY kernel; 0: one list
+    int fuse_split = 0;                  // 0: every unit through the BODY kernel (one launch); 1: plain units through the lean kernel beside it
     bool fuse_ready = false;
     int fuse_chunk_used = 0;
     uint8_t *bcode = nullptr;            // bounce codes, (nxl+2) * pitch
     uint8_t *wcls = nullptr;             // window-tile classes, nwin * (nxl+2)
+    float *halo_tab = nullptr;           // halo table of the marching kernels, (nwin+1) * (nxl+2) * 8
     MarchUnit *d_units = nullptr;        // plain units first, then body units
     size_t units_cap = 0;
     int n_plain = 0, n_body = 0, n_win = 0, body_cols = 0;
@@ -259,6 +260,7 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->stage) (void)hipFree(h->stage);
     if (h->bcode) (void)hipFree(h->bcode);
     if (h->wcls) (void)hipFree(h->wcls);
+    if (h->halo_tab) (void)hipFree(h->halo_tab);
     if (h->d_units) (void)hipFree(h->d_units);
     if (h->d_nbad) (void)hipFree(h->d_nbad);
     if (h->partials) (void)hipFree(h->partials);
@@ -320,6 +322,12 @@ static int rebuild_fuse_plan(wt_handle *h)
         HIP_TRY(hipMalloc((void **)&h->wcls, wbytes));
         h->device_bytes += (long long)wbytes;
     }
+    if (!h->halo_tab) {
+        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * sizeof(float);
+        HIP_TRY(hipMalloc((void **)&h->halo_tab, hbytes));
+        HIP_TRY(hipMemsetAsync(h->halo_tab, 0, hbytes, h->s_compute));
+        h->device_bytes += (long long)hbytes;
+    }
     if (!h->bcode) {
         HIP_TRY(hipMalloc((void **)&h->bcode, cbytes));
         HIP_TRY(hipMemsetAsync(h->bcode, 0, cbytes, h->s_compute));
@@ -337,23 +345,24 @@ static int rebuild_fuse_plan(wt_handle *h)
 
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-    const long slots = (long)prop.multiProcessorCount * 4 * 3;           // 3 resident plain waves per SIMD
+    const long slots = (long)prop.multiProcessorCount * 4 * 2;           // two resident marching waves per SIMD
     const MarchRange r = march_range(g);
     const long tiles = (long)(r.i_end - r.i_begin) * nwin;
-    // chunk length: about one resident round of units (all units of a launch run side by side, so a second,
-    // partly filled round costs a whole unit time); 24 columns keep the two re-read halo columns at 8 %
+    // chunk length (measured, tools/kmarch on 4096^2): about 1.4 resident rounds of units — enough units for the
+    // dispatcher to even out the slower body units, few enough that the two re-read halo columns of a chunk stay
+    // below 10 % of its loads; a unit count just above a whole number of rounds is the worst case
     int L = h->fuse_chunk;
     if (L <= 0) {
-        L = (int)((tiles + slots - 1) / slots);
+        L = (int)((double)tiles / (1.4 * (double)slots) + 0.5);
         if (L < 6) L = 6;
         if (L > 48) L = 48;
     }
     int Lb = h->fuse_chunk_body;
-    if (Lb <= 0) Lb = L < 16 ? (L > 4 ? L / 2 : L) : 8;
+    if (Lb <= 0) Lb = L < 16 ? (L > 4 ? L / 2 : L) : 4;
     h->fuse_chunk_used = L;
-    // measured (bench.py --fuse on 544/1056/2080-column lattices): with much fewer units than resident wave slots
-    // the marching kernels cannot fill the chip and the single-step kernel is faster
-    if (!h->fuse_force && tiles / L < slots / 2) return WT_OK;
+    // measured (bench.py --fuse on 544/1056/2080-column lattices): with fewer units than resident wave slots the
+    // marching kernels cannot fill the chip and the single-step kernel is faster
+    if (!h->fuse_force && tiles / L < slots) return WT_OK;
     const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, L, h->fuse_split ? Lb : (L > MARCH_MAX_BODY_CHUNK ? MARCH_MAX_BODY_CHUNK : L),
                                           h->fuse_split != 0, 1.0);
     const size_t total = pl.plain.size() + pl.body.size();
@@ -688,13 +697,19 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     p.fs = fptr<float>(h, h->cur);
     p.fd = fptr<float>(h, 1 - h->cur);
     p.macro = reinterpret_cast<float *>(h->macro);
-    p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls;
+    p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls; p.halo = h->halo_tab;
     p.g = g;
     p.lat_bytes = (unsigned)((size_t)9 * g.plane * 4);
+    p.nwin_total = h->n_win;
     p.fdv.tau = (float)tau; p.fdv.rtau = 1.0f / (float)tau;
     p.U0 = (float)u0;
     p.rev = (int)((h->steps_done >> 1) & 1);
     hipStream_t st = h->s_compute, sb = h->s_comm;
+    if (h->n_win > 1) {        // the step-1 populations that cross the window seams
+        const long nth = (long)(h->n_win - 1) * 2 * g.nxl;
+        if (fd) hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+        else hipLaunchKernelGGL((k_halo_rows<0>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+    }
     const bool two = h->n_plain > 0 && h->n_body > 0;
     if (two) {
         HIP_TRY(hipEventRecord(h->ev_state, st));

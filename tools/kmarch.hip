@@ -20,7 +20,7 @@ using namespace wt;
 
 struct Lattice {
     int nx, ny; Geom g; int tpc, nwin; size_t lat;
-    float *f0, *f1, *f2, *f3, *macro, *macro2; uint8_t *mask, *tiles, *bcode, *wcls;
+    float *f0, *f1, *f2, *f3, *macro, *macro2, *halo; uint8_t *mask, *tiles, *bcode, *wcls;
     std::vector<uint8_t> hmask;    // device layout (nx+2) x pitch
     std::vector<uint8_t> hwcls;
 };
@@ -43,9 +43,8 @@ __global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
     const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
     const int w = __builtin_amdgcn_readfirstlane(un.w);
     if ((MODE == 2 || MODE == 3) && w >= g.ny / 256) return;
-    const int row0 = (MODE == 2 || MODE == 3) ? w * 256 : w * MARCH_STRIDE;
+    const int row0 = (MODE == 2 || MODE == 3) ? w * 256 : w * 252;
     const int j0 = row0 + lane * 4;
-    const bool first_win = (w == 0);
     MarchAddr a;
     a.rs = march_rsrc(p.fs, p.lat_bytes); a.rd = march_rsrc(p.fd, p.lat_bytes);
     a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
@@ -70,8 +69,7 @@ __global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
     for (int c = ia; c < ib; c++) {
         V4 nxt[9];
         load9((c + 2 <= ib) ? c + 2 : c + 1, nxt);
-        if (MODE == 0) march_store<false>(a, g.ny, c, j0, lane, first_win, in, mac);
-        else {
+        {
 #pragma unroll
             for (int k = 0; k < 9; k++) bstore(a.rd, a.voff, off(k, c), in[k]);
         }
@@ -106,6 +104,7 @@ static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
     CK(hipMalloc(&L.macro, (size_t)3 * nx * g.pitch * 4)); CK(hipMalloc(&L.macro2, (size_t)3 * nx * g.pitch * 4));
     CK(hipMalloc(&L.mask, (size_t)(nx + 2) * g.pitch)); CK(hipMalloc(&L.tiles, (size_t)nx * L.tpc));
     CK(hipMalloc(&L.bcode, (size_t)(nx + 2) * g.pitch)); CK(hipMalloc(&L.wcls, (size_t)(nx + 2) * L.nwin));
+    CK(hipMalloc(&L.halo, (size_t)(L.nwin + 1) * (nx + 2) * 32)); CK(hipMemset(L.halo, 0, (size_t)(L.nwin + 1) * (nx + 2) * 32));
     L.hmask.assign((size_t)(nx + 2) * g.pitch, 0);
     auto set = [&](int x, int j) { if (x >= 0 && x < nx && j >= 0 && j < ny) L.hmask[(size_t)(x + 1) * g.pitch + j] = 1; };
     if (body >= 1) {   // rotated ellipse (an "airfoil") + a thin plate
@@ -120,7 +119,7 @@ static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
     if (body >= 2) {   // solids on every edge, isolated cells, window seams
         for (int j = ny / 5; j < ny / 5 + 9; j++) { set(0, j); set(1, j); set(nx - 1, j); set(nx - 2, j); }
         for (int x = nx / 6; x < nx / 6 + 7; x++) { set(x, 0); set(x, 1); set(x, ny - 1); set(x, ny - 2); }
-        for (int w = 1; w < L.nwin; w++) for (int d = -3; d <= 5; d++) set(nx / 2 + w * 3, w * 252 + d);
+        for (int w = 1; w < L.nwin + 1; w++) for (int d = -3; d <= 5; d++) { set(nx / 2 + w * 3, w * 252 + d); set(nx / 3 + w * 3, w * 256 + d); set(nx / 3 + w * 5 + 40, w * 256 - 1); set(nx / 3 + w * 5 + 50, w * 256); }
         unsigned long long s = 12345;
         for (int t = 0; t < (nx * ny) / 400; t++) { s = s * 6364136223846793005ULL + 1442695040888963407ULL; const int x = (int)((s >> 33) % nx); s = s * 6364136223846793005ULL + 1442695040888963407ULL; const int j = (int)((s >> 33) % ny); set(x, j); }
         set(0, 0); set(nx - 1, ny - 1); set(nx - 1, 0); set(0, ny - 1);
@@ -149,25 +148,31 @@ static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
 }
 static void free_lattice(Lattice &L)
 {
-    (void)hipFree(L.f0); (void)hipFree(L.f1); (void)hipFree(L.f2); (void)hipFree(L.f3); (void)hipFree(L.macro); (void)hipFree(L.macro2); (void)hipFree(L.mask); (void)hipFree(L.tiles); (void)hipFree(L.bcode); (void)hipFree(L.wcls);
+    (void)hipFree(L.f0); (void)hipFree(L.f1); (void)hipFree(L.f2); (void)hipFree(L.f3); (void)hipFree(L.macro); (void)hipFree(L.macro2); (void)hipFree(L.mask); (void)hipFree(L.tiles); (void)hipFree(L.bcode); (void)hipFree(L.wcls); (void)hipFree(L.halo);
 }
 
 static MarchParams march_params(const Lattice &L, const float *a, float *b, float *macro, const MarchUnit *units, int nunits, float tau, float rtau, float U0, int rev)
 {
     MarchParams p;
-    p.fs = a; p.fd = b; p.macro = macro; p.mask = L.mask; p.bcode = L.bcode; p.wcls = L.wcls; p.g = L.g;
+    p.fs = a; p.fd = b; p.macro = macro; p.mask = L.mask; p.bcode = L.bcode; p.wcls = L.wcls; p.halo = L.halo; p.g = L.g; p.nwin_total = L.nwin;
     p.units = units; p.nunits = nunits; p.lat_bytes = (unsigned)L.lat;
     p.fdv.tau = tau; p.fdv.rtau = rtau; p.U0 = U0; p.rev = rev;
     return p;
 }
+static int g_lds_bytes = 0;   // dynamic LDS per block: limits resident blocks per CU (occupancy experiments)
 // one pass = the plain units on `st`, the body units on `sb` (sb == st: one after the other)
 template <bool EMIT, int FD, int WP, int WB>
 static void march_pass(const Lattice &L, const DevPlan &d, const float *a, float *b, float *macro, float tau, float U0, int rev, hipStream_t st, hipStream_t sb, hipEvent_t ev0, hipEvent_t ev1)
 {
     const float rtau = 1.0f / tau;
+    if (L.nwin > 1) {
+        const long nth = (long)(L.nwin - 1) * 2 * L.g.nxl;
+        const FastDiv fdv{tau, rtau};
+        hipLaunchKernelGGL((k_halo_rows<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, L.halo, L.g, L.nwin, fdv, U0);
+    }
     if (sb != st) { CK(hipEventRecord(ev0, st)); CK(hipStreamWaitEvent(sb, ev0, 0)); }
-    if (d.nbody) hipLaunchKernelGGL((k_march<true, EMIT, FD, WB>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), 0, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
-    if (d.nplain) hipLaunchKernelGGL((k_march<false, EMIT, FD, WP>), dim3((unsigned)((d.nplain + 3) / 4)), dim3(256), 0, st, march_params(L, a, b, macro, d.plain, d.nplain, tau, rtau, U0, rev));
+    if (d.nbody) hipLaunchKernelGGL((k_march<true, EMIT, FD, WB>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), g_lds_bytes, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
+    if (d.nplain) hipLaunchKernelGGL((k_march<false, EMIT, FD, WP>), dim3((unsigned)((d.nplain + 3) / 4)), dim3(256), g_lds_bytes, st, march_params(L, a, b, macro, d.plain, d.nplain, tau, rtau, U0, rev));
     if (sb != st) { CK(hipEventRecord(ev1, sb)); CK(hipStreamWaitEvent(st, ev1, 0)); }
 }
 
@@ -266,31 +271,23 @@ int main(int argc, char **argv)
     std::vector<Var> vs;
     std::vector<DevPlan> plans; plans.reserve(256);
     vs.push_back({"k_step x2 (production)", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(L.f1, b, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
-    for (int order : {1}) for (int Lp : {24}) {
-        plans.push_back(upload_plan(L0, Lp, 8, order)); DevPlan *d0 = &plans.back();
-        const std::string tag = " ord=" + std::to_string(order) + " Lp=" + std::to_string(Lp) + " (" + std::to_string(d0->nplain) + ")";
-        vs.push_back({"nobody ieee" + tag, [&, d0](const float *a, float *b, int r) { march_pass<false, 0, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
-        vs.push_back({"nobody fdiv" + tag, [&, d0](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
-        vs.push_back({"nobody BODYkernel w3 ieee" + tag, [&, d0](const float *a, float *b, int r) { hipLaunchKernelGGL((k_march<true, false, 0, 3>), dim3((unsigned)((d0->nplain + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, d0->plain, d0->nplain, tau, 1.0f / tau, U0, r)); }, {}, 2});
-        vs.push_back({"nobody BODYkernel w2 ieee" + tag, [&, d0](const float *a, float *b, int r) { hipLaunchKernelGGL((k_march<true, false, 0, 2>), dim3((unsigned)((d0->nplain + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, d0->plain, d0->nplain, tau, 1.0f / tau, U0, r)); }, {}, 2});
-#define COPYV(M, label) vs.push_back({label + tag, [&, d0](const float *a, float *b, int r) { hipLaunchKernelGGL((k_march_copy<M>), dim3((unsigned)((d0->nplain + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, d0->plain, d0->nplain, tau, 1.0f / tau, U0, r)); }, {}, 2})
-        COPYV(0, std::string("copy0 march pattern      "));
-        COPYV(1, std::string("copy1 full stores        "));
-        COPYV(4, std::string("copy4 aligned loads      "));
-        COPYV(2, std::string("copy2 256-stride aligned "));
-        COPYV(3, std::string("copy3 tiled sequential   "));
+    for (int Lp : {12, 16, 24, 32, 48}) for (int occ : {1, 2, 3}) {
+        plans.push_back(upload_plan(L0, Lp, 8, 1)); DevPlan *d0 = &plans.back();
+        const int lds = occ == 3 ? 0 : (occ == 2 ? 65536 : 98304);
+        const std::string tag = " Lp=" + std::to_string(Lp) + " occ=" + std::to_string(occ) + " (" + std::to_string(d0->nplain) + ")";
+        vs.push_back({"nobody lean fdiv" + tag, [&, d0, lds](const float *a, float *b, int r) { g_lds_bytes = lds; march_pass<false, 1, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); g_lds_bytes = 0; }, {}, 2});
     }
-    for (double alpha : {0.0, 0.5, 1.0, 2.0}) for (int Lu : {16, 24, 28}) {
-        plans.push_back(upload_plan(L, Lu, Lu, 1, false, alpha)); DevPlan *d1 = &plans.back();
-        char buf[64]; snprintf(buf, sizeof buf, " a=%.1f L=%d (%d)", alpha, Lu, d1->nbody);
-        const std::string tag = buf;
-        vs.push_back({"body unified ieee w2" + tag, [&, d1](const float *a, float *b, int r) { march_pass<false, 0, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
-        vs.push_back({"body unified fdiv w2" + tag, [&, d1](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
+    for (int Lu : {12, 16, 24, 32}) for (int occ : {1, 2}) {
+        plans.push_back(upload_plan(L, Lu, Lu, 1, false, 1.0)); DevPlan *d1 = &plans.back();
+        const int lds = occ == 2 ? 0 : 98304;
+        const std::string tag = " L=" + std::to_string(Lu) + " occ=" + std::to_string(occ) + " (" + std::to_string(d1->nbody) + ")";
+        vs.push_back({"body unified fdiv a=1" + tag, [&, d1, lds](const float *a, float *b, int r) { g_lds_bytes = lds; march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); g_lds_bytes = 0; }, {}, 2});
     }
-    for (int order : {1}) for (int Lp : {16, 24}) for (int Lb : {4}) {
-        plans.push_back(upload_plan(L, Lp, Lb, order)); DevPlan *d1 = &plans.back();
-        const std::string tag = " ord=" + std::to_string(order) + " Lp=" + std::to_string(Lp) + " Lb=" + std::to_string(Lb) + " (" + std::to_string(d1->nplain) + "+" + std::to_string(d1->nbody) + ")";
-        vs.push_back({"body fdiv 2-stream" + tag, [&, d1](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, sb, ev0, ev1); }, {}, 2});
+    for (int Lp : {16, 24, 32}) for (int occ : {1, 2, 3}) {
+        plans.push_back(upload_plan(L, Lp, 4, 1, true, 1.0)); DevPlan *d1 = &plans.back();
+        const int lds = occ == 3 ? 0 : (occ == 2 ? 65536 : 98304);
+        const std::string tag = " Lp=" + std::to_string(Lp) + " Lb=4 occ=" + std::to_string(occ) + " (" + std::to_string(d1->nplain) + "+" + std::to_string(d1->nbody) + ")";
+        vs.push_back({"body split 2-stream fdiv" + tag, [&, d1, lds](const float *a, float *b, int r) { g_lds_bytes = lds; march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, sb, ev0, ev1); g_lds_bytes = 0; }, {}, 2});
     }
     if (argc > 4 && std::string(argv[4]) == "prof") {
         // one variant per kernel name, few launches: for rocprofv3 --pmc
