@@ -160,6 +160,40 @@ __device__ __forceinline__ void collide_fd(const float (&fin)[9], const FastDiv 
     uy = v;
 }
 
+// The same collision in two stages, for kernels that collide several sites per lane and want ONE decision
+// "fast or IEEE division" for all of them (a branch per site costs more than the test saves):
+//   collide_head: moments and density clamp (html:335-346); `safe` = this site may use the fast division
+//   collide_tail<FAST>: velocity clamp (html:347-350), equilibrium, relaxation (html:352-356)
+// Operation for operation the sequence of collide_fd.
+__device__ __forceinline__ void collide_head(const float (&fin)[9], float &r, float &u, float &v, float &spd2, bool &safe)
+{
+    moments(fin, r, u, v);
+    const float rhoMin = 0.5f, rhoMax = 2.0f;
+    r = (r < rhoMin) ? rhoMin : r;
+    r = (rhoMax < r) ? rhoMax : r;
+    spd2 = u * u + v * v;
+    const float m0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[0]), __builtin_fabsf(fin[1])), __builtin_fabsf(fin[2]));
+    const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[3]), __builtin_fabsf(fin[4])), __builtin_fabsf(fin[5]));
+    const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[6]), __builtin_fabsf(fin[7])), __builtin_fabsf(fin[8]));
+    const float m = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
+    safe = (m < 0x1p100f) && (r == r) && (spd2 == spd2);
+}
+
+template <bool FAST>
+__device__ __forceinline__ void collide_tail(const float (&fin)[9], const FastDiv &fd, float r, float &u, float &v, float spd2, float (&fo)[9])
+{
+    const float uMax = 0.35f;
+    if (spd2 > uMax * uMax) {
+        const float k = uMax / wt_sqrt<float>(spd2);
+        u *= k;
+        v *= k;
+    }
+    float eq[9];
+    feq_all(r, u, v, eq);
+#pragma unroll
+    for (int k = 0; k < 9; k++) fo[k] = fin[k] - (FAST ? div_by_tau_fast(fin[k] - eq[k], fd) : (fin[k] - eq[k]) / fd.tau);
+}
+
 template <typename T>
 __device__ __forceinline__ void collide(const T (&fin)[9], T tau, T (&fo)[9], T &rho, T &ux, T &uy)
 {

@@ -15,11 +15,10 @@
 // k_halo_rows fills before each pass (two rows per window seam, per-site code with every branch of
 // STEP_FS); a wave fetches its six values per column with one dword load, one iteration ahead.
 //
-// Two instantiations share the code:
-//   * BODY = false — "plain" units: no solid site inside the unit's input footprint, no inlet / outlet
-//     column.  Straight-line arithmetic, nothing but populations is read.
-//   * BODY = true — every other unit (round 1 sent these through a third lattice in two single-step
-//     passes).  Each window-tile (column x, window w) has a class (k_classify_windows, wave ballots):
+// The whole lattice is marched by ONE kernel (BODY = true; the BODY = false instantiation — plain fluid only —
+// exists for tools/kmarch, where it measured no faster).  Round 1 sent everything near the body through a
+// third lattice in two single-step passes; here each window-tile (column x, window w) has a class
+//     (k_classify_windows, wave ballots):
 //     FAST = no solid site in its 3 x 258 neighbourhood, SOLID = every own site solid, GENERAL = the rest;
 //     a unit reads the classes of its columns once (one byte per lane, two ballots -> two 64-bit scalars)
 //     and dispatches per column on a scalar bit test.  GENERAL tiles read one dword of solid flags and
@@ -35,13 +34,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <vector>
 #include "step_fast.hpp"
 
 namespace wt {
 
 static constexpr int MARCH_WIN = 256;            // window height = window pitch
-static constexpr int MARCH_MAX_BODY_CHUNK = 60;  // class bytes of columns ia-1 .. ib+1 must fit one wave
+static constexpr int MARCH_MAX_CHUNK = 60;       // class bytes of columns ia-1 .. ib+1 must fit one wave
 
 enum : uint8_t { WC_FAST = 0, WC_GENERAL = 1, WC_SOLID = 2 };
 
@@ -211,6 +211,7 @@ __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, unsigned voff,
 struct MarchAddr {
     __amdgpu_buffer_rsrc_t rs, rd, rm;   // source lattice, destination lattice, macro planes
     unsigned voff;                       // j0 * 4
+    unsigned voff_st;                    // the same for stores; lanes beyond the last row: out of range (dropped by the buffer check)
     unsigned P4, pitch4, mp4;            // plane / column / macro-plane strides in bytes
 };
 
@@ -241,20 +242,41 @@ __device__ __forceinline__ void march_load_own(const MarchAddr &a, int col, V4 (
     for (int k = 0; k < 9; k++) own[k] = bload(a.rs, a.voff, lat_off(a, k, col, 0));
 }
 
-// collide 4 sites per lane
+// collide 4 sites per lane; one wave-uniform decision between the fast and the IEEE division by tau
+template <int FD>
+__device__ __forceinline__ void march_collide4(const V4 (&fin)[9], const FastDiv &fdv, V4 (&o)[9], V4 &rho4, V4 &ux4, V4 &uy4)
+{
+    float r[4], u[4], w[4], s2[4];
+    bool safe = true;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        float a[9];
+        bool sv;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+        collide_head(a, r[v], u[v], w[v], s2[v], sv);
+        safe = safe && sv;
+    }
+    const bool fast = (FD == 2) || (FD == 1 && __ballot(!safe) == 0ULL);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        float a[9], f[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+        if (FD != 0 && fast) collide_tail<true>(a, fdv, r[v], u[v], w[v], s2[v], f);
+        else collide_tail<false>(a, fdv, r[v], u[v], w[v], s2[v], f);
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k].v[v] = f[k];
+        rho4.v[v] = r[v]; ux4.v[v] = u[v]; uy4.v[v] = w[v];
+    }
+}
+
 template <int FD, bool WANT_MACRO>
 __device__ __forceinline__ void march_collide(const V4 (&fin)[9], const FastDiv &fdv, V4 (&G)[9], V4 (&mac)[3])
 {
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        float a[9], o[9], rho, ux, uy;
-#pragma unroll
-        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
-        collide_fd<FD>(a, fdv, o, rho, ux, uy);
-#pragma unroll
-        for (int k = 0; k < 9; k++) G[k].v[v] = o[k];
-        if (WANT_MACRO) { mac[0].v[v] = rho; mac[1].v[v] = ux; mac[2].v[v] = uy; }
-    }
+    V4 rho4, ux4, uy4;
+    march_collide4<FD>(fin, fdv, G, rho4, ux4, uy4);
+    if (WANT_MACRO) { mac[0] = rho4; mac[1] = ux4; mac[2] = uy4; }
 }
 
 // rows 0 and NY-1 carry the far-field populations (html:314-322); only called for windows that hold one of them
@@ -293,21 +315,19 @@ template <int FD, bool WANT_MACRO>
 __device__ __forceinline__ void march_collide_general(const V4 (&fin)[9], uint32_t solid4, int j0, int ny, const FastDiv &fdv, float U0,
                                                       const float (&feq0)[9], V4 (&G)[9], V4 (&mac)[3])
 {
+    V4 o[9], rho4, ux4, uy4;
+    march_collide4<FD>(fin, fdv, o, rho4, ux4, uy4);
 #pragma unroll
     for (int v = 0; v < 4; v++) {
-        float a[9], o[9], rho, ux, uy;
-#pragma unroll
-        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
-        collide_fd<FD>(a, fdv, o, rho, ux, uy);
         const bool solid = ((solid4 >> (8 * v)) & 0xffu) != 0;
         const int j = j0 + v;
         const bool far = (j == 0) || (j == ny - 1);
 #pragma unroll
-        for (int k = 0; k < 9; k++) G[k].v[v] = solid ? a[k] : (far ? feq0[k] : o[k]);
+        for (int k = 0; k < 9; k++) G[k].v[v] = solid ? fin[k].v[v] : (far ? feq0[k] : o[k].v[v]);
         if (WANT_MACRO) {
-            mac[0].v[v] = (solid || far) ? 1.0f : rho;
-            mac[1].v[v] = solid ? 0.0f : (far ? U0 : ux);
-            mac[2].v[v] = (solid || far) ? 0.0f : uy;
+            mac[0].v[v] = (solid || far) ? 1.0f : rho4.v[v];
+            mac[1].v[v] = solid ? 0.0f : (far ? U0 : ux4.v[v]);
+            mac[2].v[v] = (solid || far) ? 0.0f : uy4.v[v];
         }
     }
 }
@@ -344,17 +364,19 @@ __device__ __forceinline__ void march_outlet_macro(const V4 (&q9)[9], V4 (&mac)[
     }
 }
 
-// store the window's rows of column `col` (lanes beyond the last row hold nothing)
+// store the window's rows of column `col`.  No branch: lanes beyond the last row carry an out-of-range offset and
+// the buffer range check drops their stores.  (A divergent `if (row < NY)` around the stores makes hipcc's waitcnt
+// pass merge the "stored" and "not stored" paths and drain vmcnt to 0 at the loop tail — every iteration then waits
+// for its own nine stores to complete before the next one starts.)
 template <bool EMIT>
-__device__ __forceinline__ void march_store(const MarchAddr &a, int ny, int col, int j0, const V4 (&out)[9], const V4 (&mac)[3])
+__device__ __forceinline__ void march_store(const MarchAddr &a, int col, const V4 (&out)[9], const V4 (&mac)[3])
 {
-    if (j0 >= ny) return;
 #pragma unroll
-    for (int k = 0; k < 9; k++) bstore(a.rd, a.voff, lat_off(a, k, col, 0), out[k]);
+    for (int k = 0; k < 9; k++) bstore(a.rd, a.voff_st, lat_off(a, k, col, 0), out[k]);
     if (EMIT) {
         const unsigned mo = (unsigned)col * a.pitch4;
 #pragma unroll
-        for (int q = 0; q < 3; q++) bstore(a.rm, a.voff, (unsigned)q * a.mp4 + mo, mac[q]);
+        for (int q = 0; q < 3; q++) bstore(a.rm, a.voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
     }
 }
 
@@ -399,14 +421,14 @@ __device__ __forceinline__ void march_step1(const MarchParams &p, const MarchAdd
     if (far_win) march_far_rows<false>(j0, p.g.ny, p.U0, feq0, G, mac);
 }
 
-template <bool BODY, bool EMIT, int FD, int MINW>
+template <bool BODY, bool EMIT, int FD, int MINW, int PF = 1>
 __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
 {
     const Geom &g = p.g;
     const int lane = threadIdx.x & 63;
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (u >= p.nunits) return;
-    if (p.rev) u = p.nunits - 1 - u;
+    if (p.rev & 1) u = p.nunits - 1 - u;
     const MarchUnit un = p.units[u];
     const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
     const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
@@ -418,6 +440,7 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
     a.rd = march_rsrc(p.fd, p.lat_bytes);
     a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
     a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * 4u;          // lanes beyond the last row re-read the window's first rows (cached) and store nothing
+    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * 4u : p.lat_bytes;   // >= num_records of both the lattice and the macro buffer
     a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
     // halo table: lanes 0..5 fetch, for step 2 of column c, {G2(c), G5(c-1), G6(c+1)} of the row below the window
     // (seam w) and {G4(c), G7(c+1), G8(c-1)} of the row above it (seam w+1); record = 8 floats per (seam, column)
@@ -441,6 +464,7 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
         if (lane < n) cls = p.wcls[(long)w * (g.nxl + 2) + ia + lane];
         nonfast_m = __ballot(cls != WC_FAST);
         solid_m = __ballot(cls == WC_SOLID);
+        if (p.rev & 8) { nonfast_m = 0; solid_m = 0; }       // (tools/kmarch: timing experiment, wrong results)
     }
 #define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 1)) & 1ULL) != 0)
 #define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 1)) & 1ULL) != 0)
@@ -460,10 +484,14 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
     STEP1(ia, in, Gc);
     march_load_stream(a, ia + 1, in);
     unsigned hv = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (unsigned)ia * 32u, 0);
+    V4 nxt[9];
+    if (PF == 2) march_load_stream(a, (ia + 2 <= ib) ? ia + 2 : ia + 1, nxt);
 #pragma unroll 1
     for (int c = ia; c < ib; c++) {
-        V4 nxt[9];
-        march_load_stream(a, (c + 2 <= ib) ? c + 2 : c + 1, nxt);             // prefetch (last one: harmless re-load)
+        V4 nxt2[9];
+        if (PF == 2) march_load_stream(a, (c + 3 <= ib) ? c + 3 : ib, nxt2);  // two columns ahead
+        else if (!(p.rev & 2)) march_load_stream(a, (c + 2 <= ib) ? c + 2 : c + 1, nxt);   // prefetch (last one: harmless re-load)
+        else { for (int k = 0; k < 9; k++) nxt[k] = in[k]; }                   // (tools/kmarch: arithmetic only)
         const unsigned hv_next = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (unsigned)(c + 1) * 32u, 0);
         STEP1(c + 1, in, G);                                                  // step 1 of column c+1
         const float hb2 = __uint_as_float(__builtin_amdgcn_readlane(hv, 0)), hb5 = __uint_as_float(__builtin_amdgcn_readlane(hv, 1)),
@@ -506,7 +534,7 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
             march_collide<FD, EMIT>(fin, p.fdv, out, mac);
             if (far_win) march_far_rows<EMIT>(j0, g.ny, p.U0, feq0, out, mac);
         }
-        march_store<EMIT>(a, g.ny, c, j0, out, mac);
+        if (!(p.rev & 4) || c + 1 == ib) march_store<EMIT>(a, c, out, mac);
         if (BODY && __builtin_expect((uflags & MU_OUTLET_AFTER) && c + 1 == ib, 0)) {
             // outlet column NX-1 (html:301-312): its step-2 value is the step-1 state of column NX-2 (= Gc), its own
             // step-1 state (solid sites only) is G
@@ -517,11 +545,11 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
             for (int k = 0; k < 9; k++) out[k] = Gc[k];
             if (EMIT) march_outlet_macro(Gc, mac);
             if (__ballot(solid4 != 0) != 0ULL) march_solid<EMIT>(out, mac, solid4, ownp);
-            march_store<EMIT>(a, g.ny, c + 1, j0, out, mac);
+            march_store<EMIT>(a, c + 1, out, mac);
         }
         G158m[0] = Gc[1]; G158m[1] = Gc[5]; G158m[2] = Gc[8];
 #pragma unroll
-        for (int k = 0; k < 9; k++) { Gc[k] = G[k]; in[k] = nxt[k]; }
+        for (int k = 0; k < 9; k++) { Gc[k] = G[k]; in[k] = nxt[k]; if (PF == 2) nxt[k] = nxt2[k]; }
         hv = hv_next;
     }
 #undef NONFAST
@@ -545,63 +573,63 @@ static inline MarchRange march_range(const Geom &g)
 }
 
 struct MarchPlan {
-    std::vector<MarchUnit> plain, body;
+    std::vector<MarchUnit> units;
     int nwin = 0;
+    int chunk = 0;       // columns of a typical unit
 };
 
-// wcls: host copy of the window-tile classes [nwin][nxl+2].  Per window, the marched columns split into maximal
-// runs: a column belongs to a PLAIN run when the tiles x-1, x, x+1 are FAST and neither x-1 nor x+1 is an inlet /
-// outlet column, else to a BODY run (split = false: one BODY run per window).  A run is cut into units of about
-// equal COST, at most Lp (plain) or Lb (body) cost units each: a FAST column costs 1, any other column 1 + alpha
-// (its step 1 waits for nine more loads); all units of a launch are resident at once, so the launch takes as long
-// as its most expensive unit.
-static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int Lp, int Lb, bool split = true, double alpha = 1.0)
+// wcls: host copy of the window-tile classes [nwin][nxl+2].  All units of a launch run side by side in whole
+// "rounds" of `slots` resident waves and take about equally long, so the launch time is rounds x unit time:
+// a unit count just above a multiple of `slots` wastes most of a round (measured on 4096^2: 4096 units 126 us
+// per step, 4298 units 162 us).  The marched columns of every window are therefore cut into units of equal
+// COST — a FAST column costs 1, any other column 1 + alpha (its step 1 waits for nine more loads) — such that
+// the total is at most `target_units` (a multiple of `slots` chosen by the caller), or, when max_cost > 0, into
+// units of at most max_cost (tests, experiments).
+static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, long target_units, int max_cost = 0, double alpha = 1.0)
 {
     MarchPlan pl;
     const int nwin = march_nwin(g.ny), ld = g.nxl + 2;
     pl.nwin = nwin;
     const MarchRange r = march_range(g);
-    if (Lb > MARCH_MAX_BODY_CHUNK) Lb = MARCH_MAX_BODY_CHUNK;
-    if (Lp < 1) Lp = 1;
-    if (Lb < 1) Lb = 1;
+    const int ncol = r.i_end - r.i_begin;
+    if (ncol <= 0) return pl;
+    std::vector<double> wcost((size_t)nwin, 0.0);
+    double total = 0.0;
     for (int w = 0; w < nwin; w++) {
-        const uint8_t *c = wcls + (size_t)w * ld + 1;       // c[x], x = -1 .. nxl
-        auto is_plain = [&](int x) {
-            const int gi = x + g.gi0;
-            if (!split) return false;                        // one list: every unit through the BODY kernel
-            if (gi <= 1 || gi >= g.nx_g - 2) return false;   // step 1 of x-1 / x+1 must not be the inlet / outlet column
-            return c[x - 1] == WC_FAST && c[x] == WC_FAST && c[x + 1] == WC_FAST;
-        };
-        auto cost = [&](int x) { return c[x] == WC_FAST ? 1.0 : 1.0 + alpha; };
-        auto cut = [&](std::vector<MarchUnit> &dst, int a, int b, int Lmax, int maxcols, bool outlet) {
-            double total = 0.0;
-            for (int x = a; x < b; x++) total += cost(x);
-            int parts = (int)((total + Lmax - 1e-9) / Lmax);
-            if (parts < 1) parts = 1;
-            const double target = total / parts;
-            int ia = a;
-            double acc = 0.0;
-            int done = 0;
-            for (int x = a; x < b; x++) {
-                acc += cost(x);
-                const bool last = (x + 1 == b);
-                if (last || acc >= target * (done + 1) - 1e-9 || x + 1 - ia >= maxcols) {
-                    dst.push_back(MarchUnit{ia, x + 1, w, (outlet && last) ? MU_OUTLET_AFTER : 0});
-                    ia = x + 1;
-                    done++;
-                }
+        const uint8_t *c = wcls + (size_t)w * ld + 1;
+        for (int x = r.i_begin; x < r.i_end; x++) wcost[w] += (c[x] == WC_FAST) ? 1.0 : 1.0 + alpha;
+        total += wcost[w];
+    }
+    double target;       // cost of one unit
+    if (max_cost > 0) target = (double)max_cost;
+    else {
+        if (target_units < nwin) target_units = nwin;
+        target = total / (double)target_units;
+    }
+    if (target > (double)MARCH_MAX_CHUNK) target = (double)MARCH_MAX_CHUNK;      // a unit's class bytes must fit one wave
+    if (target < 1.0) target = 1.0;
+    pl.chunk = (int)(target + 0.5);
+    for (int w = 0; w < nwin; w++) {
+        const uint8_t *c = wcls + (size_t)w * ld + 1;
+        // whole parts only, never more than wcost / target of them: the total stays <= target_units
+        int parts = (int)(wcost[w] / target);
+        if (max_cost > 0) parts = (int)((wcost[w] + target - 1e-9) / target);
+        if (parts < 1) parts = 1;
+        const double per = wcost[w] / parts;
+        int ia = r.i_begin, done = 0;
+        double acc = 0.0;
+        for (int x = r.i_begin; x < r.i_end; x++) {
+            acc += (c[x] == WC_FAST) ? 1.0 : 1.0 + alpha;
+            const bool last = (x + 1 == r.i_end);
+            if (last || (done + 1 < parts && acc >= per * (done + 1) - 1e-9) || x + 1 - ia >= MARCH_MAX_CHUNK) {
+                pl.units.push_back(MarchUnit{ia, x + 1, w, (r.outlet_after && last) ? MU_OUTLET_AFTER : 0});
+                ia = x + 1;
+                done++;
             }
-        };
-        int x = r.i_begin;
-        while (x < r.i_end) {
-            const bool pln = is_plain(x);
-            int e = x + 1;
-            while (e < r.i_end && is_plain(e) == pln) e++;
-            if (pln) cut(pl.plain, x, e, Lp, 1 << 30, false);
-            else cut(pl.body, x, e, Lb, MARCH_MAX_BODY_CHUNK, r.outlet_after && e == r.i_end);
-            x = e;
         }
     }
+    // chunk-major order: the windows of one chunk are neighbours in the list (adjacent waves read adjacent kilobytes)
+    std::stable_sort(pl.units.begin(), pl.units.end(), [](const MarchUnit &x, const MarchUnit &y) { return x.ia != y.ia ? x.ia < y.ia : x.w < y.w; });
     return pl;
 }
 

@@ -93,17 +93,15 @@ struct wt_handle {
     // two-steps-per-launch mode (step_march.hpp); fp32 handles with NY % 4 == 0
     bool fuse = false;
     bool fuse_force = false;             // fuse_steps = 2: also when the lattice is too small for it to pay
-    int fuse_chunk = 0;                  // plain-unit cost limit; 0 = chosen from the lattice size
-    int fuse_chunk_body = 0;             // body-unit cost limit; 0 = automatic
-    int fuse_split = 0;                  // 0: every unit through the BODY kernel (one launch); 1: plain units through the lean kernel beside it
+    int fuse_chunk = 0;                  // cost limit of a unit (columns); 0 = whole resident rounds of units (build_march_plan)
     bool fuse_ready = false;
     int fuse_chunk_used = 0;
     uint8_t *bcode = nullptr;            // bounce codes, (nxl+2) * pitch
     uint8_t *wcls = nullptr;             // window-tile classes, nwin * (nxl+2)
     float *halo_tab = nullptr;           // halo table of the marching kernels, (nwin+1) * (nxl+2) * 8
-    MarchUnit *d_units = nullptr;        // plain units first, then body units
+    MarchUnit *d_units = nullptr;
     size_t units_cap = 0;
-    int n_plain = 0, n_body = 0, n_win = 0, body_cols = 0;
+    int n_units = 0, n_win = 0, nonfast_tiles = 0;
     std::vector<uint8_t> host_wcls;
     // fast division by tau (d2q9.hpp): proved per tau on the device before it is used
     unsigned int *d_nbad = nullptr;
@@ -224,8 +222,6 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
         if (e) { h->fuse = atoi(e) != 0; h->fuse_force = atoi(e) >= 2; }
         const char *c = getenv("WT_FUSE_CHUNK");
         if (c && atoi(c) >= 0) h->fuse_chunk = atoi(c);
-        const char *sp = getenv("WT_FUSE_SPLIT");
-        if (sp) h->fuse_split = atoi(sp) != 0;
         const char *fdv = getenv("WT_FAST_DIV");
         if (fdv) h->fast_div = atoi(fdv) != 0;
     }
@@ -304,7 +300,7 @@ extern "C" int wt_sync(wt_handle *h)
 // marching kernels address a lattice through one 32-bit buffer descriptor
 static bool fuse_eligible(const wt_handle *h)
 {
-    return h->dtype == WT_F32 && h->g.ny % 4 == 0 && h->g.nxl >= 8 && (unsigned long long)9 * h->g.plane * 4ULL < (1ULL << 32);
+    return h->dtype == WT_F32 && h->g.ny % 4 == 0 && h->g.nxl >= 8 && (unsigned long long)9 * h->g.plane * 4ULL < (1ULL << 32) - (1ULL << 20);
 }
 
 // Classes, bounce codes and the unit lists of the current mask.  Everything but the two cuts of the
@@ -312,7 +308,7 @@ static bool fuse_eligible(const wt_handle *h)
 static int rebuild_fuse_plan(wt_handle *h)
 {
     h->fuse_ready = false;
-    h->n_plain = h->n_body = h->body_cols = 0;
+    h->n_units = h->nonfast_tiles = 0;
     if (!h->fuse || !fuse_eligible(h) || !h->mask_set) return WT_OK;
     const Geom &g = h->g;
     const int nwin = march_nwin(g.ny);
@@ -348,24 +344,15 @@ static int rebuild_fuse_plan(wt_handle *h)
     const long slots = (long)prop.multiProcessorCount * 4 * 2;           // two resident marching waves per SIMD
     const MarchRange r = march_range(g);
     const long tiles = (long)(r.i_end - r.i_begin) * nwin;
-    // chunk length (measured, tools/kmarch on 4096^2): about 1.4 resident rounds of units — enough units for the
-    // dispatcher to even out the slower body units, few enough that the two re-read halo columns of a chunk stay
-    // below 10 % of its loads; a unit count just above a whole number of rounds is the worst case
-    int L = h->fuse_chunk;
-    if (L <= 0) {
-        L = (int)((double)tiles / (1.4 * (double)slots) + 0.5);
-        if (L < 6) L = 6;
-        if (L > 48) L = 48;
-    }
-    int Lb = h->fuse_chunk_body;
-    if (Lb <= 0) Lb = L < 16 ? (L > 4 ? L / 2 : L) : 4;
-    h->fuse_chunk_used = L;
-    // measured (bench.py --fuse on 544/1056/2080-column lattices): with fewer units than resident wave slots the
-    // marching kernels cannot fill the chip and the single-step kernel is faster
-    if (!h->fuse_force && tiles / L < slots) return WT_OK;
-    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, L, h->fuse_split ? Lb : (L > MARCH_MAX_BODY_CHUNK ? MARCH_MAX_BODY_CHUNK : L),
-                                          h->fuse_split != 0, 1.0);
-    const size_t total = pl.plain.size() + pl.body.size();
+    // Whole resident rounds of units (see build_march_plan): two rounds where that leaves at least 12 columns per
+    // unit (4096^2: 4096 units of 16 columns; the two re-read halo columns of a unit are then 12 % of its loads), else
+    // one.  Measured (bench.py --nx 544/1056/2080 --fuse 2): with fewer than one round of 6-column units the marching
+    // kernel cannot fill the chip and the single-step kernel is faster.
+    long target = 2 * slots;
+    if (tiles / target < 12) target = slots;
+    if (!h->fuse_force && h->fuse_chunk <= 0 && tiles / target < 6) return WT_OK;
+    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, target, h->fuse_chunk, 2.0);
+    const size_t total = pl.units.size();
     if (total == 0) return WT_OK;
     if (total > h->units_cap) {
         if (h->d_units) { HIP_TRY(hipFree(h->d_units)); h->d_units = nullptr; h->units_cap = 0; }
@@ -373,18 +360,12 @@ static int rebuild_fuse_plan(wt_handle *h)
         HIP_TRY(hipMalloc((void **)&h->d_units, cap * sizeof(MarchUnit)));
         h->units_cap = cap;
     }
-    // chunk-major order: the windows of one chunk are neighbours in the list (adjacent waves read adjacent kilobytes)
-    std::vector<MarchUnit> all(pl.plain);
-    auto cmp = [](const MarchUnit &x, const MarchUnit &y) { return x.ia != y.ia ? x.ia < y.ia : x.w < y.w; };
-    std::stable_sort(all.begin(), all.end(), cmp);
-    std::vector<MarchUnit> body(pl.body);
-    std::stable_sort(body.begin(), body.end(), cmp);
-    all.insert(all.end(), body.begin(), body.end());
-    HIP_TRY(hipMemcpyAsync(h->d_units, all.data(), total * sizeof(MarchUnit), hipMemcpyHostToDevice, h->s_compute));
+    HIP_TRY(hipMemcpyAsync(h->d_units, pl.units.data(), total * sizeof(MarchUnit), hipMemcpyHostToDevice, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    h->n_plain = (int)pl.plain.size();
-    h->n_body = (int)pl.body.size();
-    for (const MarchUnit &u : pl.body) h->body_cols += u.ib - u.ia;
+    h->n_units = (int)total;
+    h->fuse_chunk_used = pl.chunk;
+    for (int w = 0; w < nwin; w++)
+        for (int x = r.i_begin; x < r.i_end; x++) h->nonfast_tiles += h->host_wcls[(size_t)w * (g.nxl + 2) + x + 1] != WC_FAST;
     h->fuse_ready = true;
     return WT_OK;
 }
@@ -406,15 +387,6 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->fuse_chunk = (int)value;
         return rebuild_fuse_plan(h);
     }
-    if (strcmp(name, "fuse_chunk_body") == 0) {
-        if (!(value >= 0.0 && value <= 4096.0)) return fail(WT_ERR_ARG, "fuse_chunk_body out of range (0 = automatic)");
-        h->fuse_chunk_body = (int)value;
-        return rebuild_fuse_plan(h);
-    }
-    if (strcmp(name, "fuse_split") == 0) {
-        h->fuse_split = value != 0.0 ? 1 : 0;
-        return rebuild_fuse_plan(h);
-    }
     if (strcmp(name, "fast_div") == 0) {
         h->fast_div = value != 0.0;
         return WT_OK;
@@ -429,11 +401,8 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "fuse_steps") == 0) { *value = h->fuse ? (h->fuse_force ? 2.0 : 1.0) : 0.0; return WT_OK; }
     if (strcmp(name, "fuse_active") == 0) { *value = h->fuse_ready ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_ready ? h->fuse_chunk_used : h->fuse_chunk; return WT_OK; }
-    if (strcmp(name, "fuse_chunk_body") == 0) { *value = h->fuse_chunk_body; return WT_OK; }
-    if (strcmp(name, "fuse_split") == 0) { *value = h->fuse_split; return WT_OK; }
-    if (strcmp(name, "fuse_units") == 0) { *value = h->n_plain + h->n_body; return WT_OK; }
-    if (strcmp(name, "fuse_units_body") == 0) { *value = h->n_body; return WT_OK; }
-    if (strcmp(name, "fuse_tiles_single") == 0) { *value = h->body_cols; return WT_OK; }   // window-tiles marched by the BODY kernel
+    if (strcmp(name, "fuse_units") == 0) { *value = h->n_units; return WT_OK; }
+    if (strcmp(name, "fuse_tiles_general") == 0) { *value = h->nonfast_tiles; return WT_OK; }   // window-tiles that take the body paths
     if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
@@ -671,23 +640,20 @@ static int fastdiv_for(wt_handle *h, float tau, bool *use)
     return WT_OK;
 }
 
-template <bool BODY, bool EMIT, int FD>
+template <bool EMIT, int FD>
 static void launch_march(const MarchParams &p, hipStream_t st)
 {
     if (p.nunits <= 0) return;
-    hipLaunchKernelGGL((k_march<BODY, EMIT, FD, 2>), dim3((unsigned)((p.nunits + 3) / 4)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_march<true, EMIT, FD, 2>), dim3((unsigned)((p.nunits + 3) / 4)), dim3(256), 0, st, p);
 }
 
-template <bool BODY>
 static void launch_march_any(const MarchParams &p, bool emit, bool fd, hipStream_t st)
 {
-    if (emit) { if (fd) launch_march<BODY, true, 1>(p, st); else launch_march<BODY, true, 0>(p, st); }
-    else { if (fd) launch_march<BODY, false, 1>(p, st); else launch_march<BODY, false, 0>(p, st); }
+    if (emit) { if (fd) launch_march<true, 1>(p, st); else launch_march<true, 0>(p, st); }
+    else { if (fd) launch_march<false, 1>(p, st); else launch_march<false, 0>(p, st); }
 }
 
 // Two steps in one pass over the lattice (step_march.hpp).  A = f[cur] (time t), B = f[1-cur] (receives time t+2).
-// The body units (BODY kernel) run on the second stream beside the plain units: both only read A and write
-// disjoint sites of B.
 static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
 {
     const Geom &g = h->g;
@@ -704,29 +670,14 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     p.fdv.tau = (float)tau; p.fdv.rtau = 1.0f / (float)tau;
     p.U0 = (float)u0;
     p.rev = (int)((h->steps_done >> 1) & 1);
-    hipStream_t st = h->s_compute, sb = h->s_comm;
+    hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // the step-1 populations that cross the window seams
         const long nth = (long)(h->n_win - 1) * 2 * g.nxl;
         if (fd) hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, h->halo_tab, g, h->n_win, p.fdv, p.U0);
         else hipLaunchKernelGGL((k_halo_rows<0>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, h->halo_tab, g, h->n_win, p.fdv, p.U0);
     }
-    const bool two = h->n_plain > 0 && h->n_body > 0;
-    if (two) {
-        HIP_TRY(hipEventRecord(h->ev_state, st));
-        HIP_TRY(hipStreamWaitEvent(sb, h->ev_state, 0));
-    }
-    if (h->n_body > 0) {
-        p.units = h->d_units + h->n_plain; p.nunits = h->n_body;
-        launch_march_any<true>(p, emit, fd, two ? sb : st);
-    }
-    if (h->n_plain > 0) {
-        p.units = h->d_units; p.nunits = h->n_plain;
-        launch_march_any<false>(p, emit, fd, st);
-    }
-    if (two) {
-        HIP_TRY(hipEventRecord(h->ev_halo, sb));
-        HIP_TRY(hipStreamWaitEvent(st, h->ev_halo, 0));
-    }
+    p.units = h->d_units; p.nunits = h->n_units;
+    launch_march_any(p, emit, fd, st);
     HIP_TRY(hipGetLastError());
     h->cur = 1 - h->cur;
     h->steps_done += 2;

@@ -86,8 +86,9 @@ def test_fused_toggle_midrun_and_4096(pkg):
         b.set_option("fuse_steps", 2)            # option set after the mask: the plan is rebuilt from the kept copy
         assert b.get_option("fuse_active") == 1.0
         b.step(4, 0.58, 0.06)
-        assert b.get_option("fuse_units_body") > 0 and b.get_option("fast_div_active") == 1.0
-        assert 0 < b.get_option("fuse_tiles_single") <= nx * (ny // 256)      # window-tiles marched by the BODY kernel
+        assert b.get_option("fast_div_active") == 1.0
+        assert 0 < b.get_option("fuse_tiles_general") < 0.15 * nx * (ny // 256)      # window-tiles that take the body paths
+        assert b.get_option("fuse_units") <= 2 * 256 * 8                             # whole resident rounds of units
         b.set_option("fuse_steps", 0)
         b.step(2, 0.58, 0.06)
         assert bits_equal(a.read_f(), b.read_f())

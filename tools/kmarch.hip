@@ -79,16 +79,11 @@ __global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
 }
 
 struct DevPlan { MarchUnit *plain = nullptr, *body = nullptr; int nplain = 0, nbody = 0; };
-static DevPlan upload_plan(const Lattice &L, int Lp, int Lb, int order = 0, bool split = true, double alpha = 1.0)
+static DevPlan upload_plan(const Lattice &L, long target_units, int max_cost = 0, double alpha = 1.0)
 {
-    MarchPlan pl = build_march_plan(L.hwcls.data(), L.g, Lp, Lb, split, alpha);
-    if (order == 1) {   // chunk-major: adjacent windows of one chunk are neighbours in the list
-        auto cmp = [](const MarchUnit &x, const MarchUnit &y) { return x.ia != y.ia ? x.ia < y.ia : x.w < y.w; };
-        std::stable_sort(pl.plain.begin(), pl.plain.end(), cmp); std::stable_sort(pl.body.begin(), pl.body.end(), cmp);
-    }
-    DevPlan d; d.nplain = (int)pl.plain.size(); d.nbody = (int)pl.body.size();
-    if (d.nplain) { CK(hipMalloc(&d.plain, sizeof(MarchUnit) * d.nplain)); CK(hipMemcpy(d.plain, pl.plain.data(), sizeof(MarchUnit) * d.nplain, hipMemcpyHostToDevice)); }
-    if (d.nbody) { CK(hipMalloc(&d.body, sizeof(MarchUnit) * d.nbody)); CK(hipMemcpy(d.body, pl.body.data(), sizeof(MarchUnit) * d.nbody, hipMemcpyHostToDevice)); }
+    const MarchPlan pl = build_march_plan(L.hwcls.data(), L.g, target_units, max_cost, alpha);
+    DevPlan d; d.nbody = (int)pl.units.size();
+    if (d.nbody) { CK(hipMalloc(&d.body, sizeof(MarchUnit) * d.nbody)); CK(hipMemcpy(d.body, pl.units.data(), sizeof(MarchUnit) * d.nbody, hipMemcpyHostToDevice)); }
     return d;
 }
 static void free_plan(DevPlan &d) { if (d.plain) (void)hipFree(d.plain); if (d.body) (void)hipFree(d.body); }
@@ -161,7 +156,7 @@ static MarchParams march_params(const Lattice &L, const float *a, float *b, floa
 }
 static int g_lds_bytes = 0;   // dynamic LDS per block: limits resident blocks per CU (occupancy experiments)
 // one pass = the plain units on `st`, the body units on `sb` (sb == st: one after the other)
-template <bool EMIT, int FD, int WP, int WB>
+template <bool EMIT, int FD, int WP, int WB, int PF = 1>
 static void march_pass(const Lattice &L, const DevPlan &d, const float *a, float *b, float *macro, float tau, float U0, int rev, hipStream_t st, hipStream_t sb, hipEvent_t ev0, hipEvent_t ev1)
 {
     const float rtau = 1.0f / tau;
@@ -171,8 +166,8 @@ static void march_pass(const Lattice &L, const DevPlan &d, const float *a, float
         hipLaunchKernelGGL((k_halo_rows<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, L.halo, L.g, L.nwin, fdv, U0);
     }
     if (sb != st) { CK(hipEventRecord(ev0, st)); CK(hipStreamWaitEvent(sb, ev0, 0)); }
-    if (d.nbody) hipLaunchKernelGGL((k_march<true, EMIT, FD, WB>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), g_lds_bytes, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
-    if (d.nplain) hipLaunchKernelGGL((k_march<false, EMIT, FD, WP>), dim3((unsigned)((d.nplain + 3) / 4)), dim3(256), g_lds_bytes, st, march_params(L, a, b, macro, d.plain, d.nplain, tau, rtau, U0, rev));
+    if (d.nbody) hipLaunchKernelGGL((k_march<true, EMIT, FD, WB, PF>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), g_lds_bytes, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
+    if (d.nplain) hipLaunchKernelGGL((k_march<false, EMIT, FD, WP, PF>), dim3((unsigned)((d.nplain + 3) / 4)), dim3(256), g_lds_bytes, st, march_params(L, a, b, macro, d.plain, d.nplain, tau, rtau, U0, rev));
     if (sb != st) { CK(hipEventRecord(ev1, sb)); CK(hipStreamWaitEvent(st, ev1, 0)); }
 }
 
@@ -199,7 +194,8 @@ static void check_case(int nx, int ny, int body, int Lp, int Lb, float tau, hipS
     step_columns<float, 3>(L.f0, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st);
     step_columns<float, 3>(L.f1, L.f2, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, true, 1, st);
     CK(hipStreamSynchronize(st)); CK(hipGetLastError());
-    DevPlan d = upload_plan(L, Lp, Lb);
+    DevPlan d = upload_plan(L, 0, Lb);
+    (void)Lp;
     for (int variant = 0; variant < 2; variant++) {
         CK(hipMemset(L.f3, 0xff, L.lat)); CK(hipMemset(L.macro2, 0xff, (size_t)3 * nx * L.g.pitch * 4));
         if (variant == 0) march_pass<true, 0, 2, 2>(L, d, L.f0, L.f3, L.macro2, tau, U0, 0, st, st, ev0, ev1);
@@ -254,16 +250,11 @@ int main(int argc, char **argv)
         step_columns<float, 3>(L.f0, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st);
         step_columns<float, 3>(L.f1, L.f2, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st);
         CK(hipMemset(L.f3, 0xff, L.lat));
-        DevPlan d = upload_plan(L, 24, 8);
-        march_pass<false, 1, 2, 2>(L, d, L.f0, L.f3, L.macro2, tau, U0, 0, st, sb, ev0, ev1);
-        CK(hipStreamSynchronize(st)); CK(hipGetLastError());
-        printf("check %dx%d body Lp=24 Lb=8 fastdiv: plain %d body %d units; %ld f values differ\n", nx, ny, d.nplain, d.nbody, compare(L, L.f2, L.f3, 9, L.g.plane, "f"));
-        free_plan(d);
-        DevPlan du = upload_plan(L, 24, 24, 1, false);
+        DevPlan du = upload_plan(L, 4096);
         CK(hipMemset(L.f3, 0xff, L.lat));
         march_pass<false, 1, 2, 2>(L, du, L.f0, L.f3, L.macro2, tau, U0, 1, st, st, ev0, ev1);
         CK(hipStreamSynchronize(st)); CK(hipGetLastError());
-        printf("check %dx%d body unified L=24 fastdiv: %d units; %ld f values differ\n", nx, ny, du.nbody, compare(L, L.f2, L.f3, 9, L.g.plane, "f"));
+        printf("check %dx%d body, 4096 units fastdiv: %d units; %ld f values differ\n", nx, ny, du.nbody, compare(L, L.f2, L.f3, 9, L.g.plane, "f"));
         free_plan(du);
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -271,33 +262,27 @@ int main(int argc, char **argv)
     std::vector<Var> vs;
     std::vector<DevPlan> plans; plans.reserve(256);
     vs.push_back({"k_step x2 (production)", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(L.f1, b, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
-    for (int Lp : {12, 16, 24, 32, 48}) for (int occ : {1, 2, 3}) {
-        plans.push_back(upload_plan(L0, Lp, 8, 1)); DevPlan *d0 = &plans.back();
-        const int lds = occ == 3 ? 0 : (occ == 2 ? 65536 : 98304);
-        const std::string tag = " Lp=" + std::to_string(Lp) + " occ=" + std::to_string(occ) + " (" + std::to_string(d0->nplain) + ")";
-        vs.push_back({"nobody lean fdiv" + tag, [&, d0, lds](const float *a, float *b, int r) { g_lds_bytes = lds; march_pass<false, 1, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); g_lds_bytes = 0; }, {}, 2});
+    for (long U : {2048L, 4096L, 6144L, 8192L}) {
+        plans.push_back(upload_plan(L0, U)); DevPlan *d0 = &plans.back();
+        vs.push_back({"nobody, target " + std::to_string(U) + " units (" + std::to_string(d0->nbody) + ")", [&, d0](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
+        for (double alpha : {0.5, 1.0, 2.0}) {
+            plans.push_back(upload_plan(L, U, 0, alpha)); DevPlan *d1 = &plans.back();
+            char buf[96]; snprintf(buf, sizeof buf, "body a=%.1f, target %ld units (%d)", alpha, U, d1->nbody);
+            vs.push_back({buf, [&, d1](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
+        }
     }
-    for (int Lu : {12, 16, 24, 32}) for (int occ : {1, 2}) {
-        plans.push_back(upload_plan(L, Lu, Lu, 1, false, 1.0)); DevPlan *d1 = &plans.back();
-        const int lds = occ == 2 ? 0 : 98304;
-        const std::string tag = " L=" + std::to_string(Lu) + " occ=" + std::to_string(occ) + " (" + std::to_string(d1->nbody) + ")";
-        vs.push_back({"body unified fdiv a=1" + tag, [&, d1, lds](const float *a, float *b, int r) { g_lds_bytes = lds; march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); g_lds_bytes = 0; }, {}, 2});
-    }
-    for (int Lp : {16, 24, 32}) for (int occ : {1, 2, 3}) {
-        plans.push_back(upload_plan(L, Lp, 4, 1, true, 1.0)); DevPlan *d1 = &plans.back();
-        const int lds = occ == 3 ? 0 : (occ == 2 ? 65536 : 98304);
-        const std::string tag = " Lp=" + std::to_string(Lp) + " Lb=4 occ=" + std::to_string(occ) + " (" + std::to_string(d1->nplain) + "+" + std::to_string(d1->nbody) + ")";
-        vs.push_back({"body split 2-stream fdiv" + tag, [&, d1, lds](const float *a, float *b, int r) { g_lds_bytes = lds; march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, sb, ev0, ev1); g_lds_bytes = 0; }, {}, 2});
+    for (int mc : {12, 16, 24}) {
+        plans.push_back(upload_plan(L, 0, mc, 1.0)); DevPlan *d1 = &plans.back();
+        vs.push_back({"body a=1, max cost " + std::to_string(mc) + " (" + std::to_string(d1->nbody) + ")", [&, d1](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
     }
     if (argc > 4 && std::string(argv[4]) == "prof") {
         // one variant per kernel name, few launches: for rocprofv3 --pmc
-        DevPlan dp = upload_plan(L0, 24, 8, 1);
+        DevPlan dp = upload_plan(L0, 4096);
         for (int q = 0; q < 6; q++) {
             const float *a = (q & 1) ? L0.f3 : L0.f0; float *b = (q & 1) ? L0.f0 : L0.f3;
             march_pass<false, 0, 2, 2>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
             march_pass<false, 1, 2, 2>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
-            march_pass<false, 2, 2, 2>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
-            hipLaunchKernelGGL((k_march_copy<1>), dim3((unsigned)((dp.nplain + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, dp.plain, dp.nplain, tau, 1.0f / tau, U0, q & 1));
+            hipLaunchKernelGGL((k_march_copy<2>), dim3((unsigned)((dp.nbody + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, dp.body, dp.nbody, tau, 1.0f / tau, U0, q & 1));
             step_columns<float, 3>(a, b, L0.macro, L0.mask, L0.tiles, L0.tpc, L0.g, 0, nx, tau, U0, false, q & 1, st);
         }
         CK(hipStreamSynchronize(st)); CK(hipGetLastError());
