@@ -128,23 +128,50 @@ __device__ __forceinline__ void site_step1(const float *__restrict__ s, const ui
 // H[(b * (nxl+2) + x + 1) * 8 + ...], seam b = 1 .. nwin-1 lies between rows 256b-1 and 256b:
 //   [0..2] = step-1 populations 2,5,6 of row 256b-1 (they move up into window b),
 //   [4..6] = step-1 populations 4,7,8 of row 256b   (they move down into window b-1).
+// One thread per (seam, column) computes both rows.  Plain fluid sites (no solid neighbour, interior column — the
+// bounce codes say so) take nine 16-byte loads: rows 256b-2 .. 256b+1 of each direction's upstream column hold every
+// input of the two sites; anything else falls back to site_step1.  The loads are a gather (neighbouring threads are
+// one column = pitch * 4 bytes apart); that, not the arithmetic, is this kernel's cost.
 template <int FD>
-__global__ __launch_bounds__(256) void k_halo_rows(const float *__restrict__ fs, const uint8_t *__restrict__ mask, float *__restrict__ halo,
-                                                   Geom g, int nwin, FastDiv fdv, float U0)
+__global__ __launch_bounds__(256) void k_halo_rows(const float *__restrict__ fs, const uint8_t *__restrict__ mask, const uint8_t *__restrict__ bcode,
+                                                   float *__restrict__ halo, Geom g, int nwin, FastDiv fdv, float U0)
 {
-    const long total = (long)(nwin - 1) * 2 * g.nxl;
+    const long total = (long)(nwin - 1) * g.nxl;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    const int x = (int)(t % g.nxl);
-    const int r = (int)(t / g.nxl);
-    const int side = r & 1, b = 1 + (r >> 1);
-    const int j = MARCH_WIN * b - 1 + side;
+    // neighbouring threads take the seams of ONE column, 1 KiB apart (neighbouring columns, pitch * 4 bytes apart, measured
+    // the same: the kernel is bound by the rate of scattered 64-byte fetches, ~130 MB of them per 4096^2 lattice)
+    const int b = 1 + (int)(t % (nwin - 1));
+    const int x = (int)(t / (nwin - 1));
+    const int j = MARCH_WIN * b - 1;                 // rows j (below the seam) and j + 1 (above it)
     if (j >= g.ny) return;
-    float out[9];
-    site_step1<FD>(fs + g.pitch, mask + g.pitch, g, x, j, fdv, U0, out);
-    float *rec = halo + ((long)b * (g.nxl + 2) + x + 1) * 8;
-    if (side == 0) { rec[0] = out[2]; rec[1] = out[5]; rec[2] = out[6]; }
-    else { rec[4] = out[4]; rec[5] = out[7]; rec[6] = out[8]; }
+    const float *s = fs + g.pitch;
+    const uint8_t *m = mask + g.pitch;
+    const long c = (long)x * g.pitch + j;
+    const int gi = x + g.gi0;
+    float lo[9], hi[9];
+    const bool two = (j + 1 < g.ny);
+    const bool plain = two && gi > 0 && gi < g.nx_g - 1 && j + 1 < g.ny - 1 &&
+                       bcode[c] == 0 && bcode[c + 1] == 0 && m[c] == 0 && m[c + 1] == 0;
+    if (plain) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        float a[9], d[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const f4u q = *reinterpret_cast<const f4u *>(s + k * g.plane + c - (long)ex_of(k) * g.pitch - 1);     // rows j-1 .. j+2
+            a[k] = q[1 - ey_of(k)];      // input of row j
+            d[k] = q[2 - ey_of(k)];      // input of row j+1
+        }
+        collide_fd<FD>(a, fdv, lo, rho, ux, uy);
+        collide_fd<FD>(d, fdv, hi, rho, ux, uy);
+    } else {
+        site_step1<FD>(s, m, g, x, j, fdv, U0, lo);
+        if (two) site_step1<FD>(s, m, g, x, j + 1, fdv, U0, hi);
+        else { for (int k = 0; k < 9; k++) hi[k] = 0.0f; }
+    }
+    float4 *rec = reinterpret_cast<float4 *>(halo + ((long)b * (g.nxl + 2) + x + 1) * 8);
+    rec[0] = make_float4(lo[2], lo[5], lo[6], 0.0f);
+    rec[1] = make_float4(hi[4], hi[7], hi[8], 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------

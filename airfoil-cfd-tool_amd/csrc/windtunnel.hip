@@ -672,9 +672,9 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     p.rev = (int)((h->steps_done >> 1) & 1);
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // the step-1 populations that cross the window seams
-        const long nth = (long)(h->n_win - 1) * 2 * g.nxl;
-        if (fd) hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, h->halo_tab, g, h->n_win, p.fdv, p.U0);
-        else hipLaunchKernelGGL((k_halo_rows<0>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+        const long nth = (long)(h->n_win - 1) * g.nxl;
+        if (fd) hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, (const uint8_t *)h->bcode, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+        else hipLaunchKernelGGL((k_halo_rows<0>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, (const uint8_t *)h->bcode, h->halo_tab, g, h->n_win, p.fdv, p.U0);
     }
     p.units = h->d_units; p.nunits = h->n_units;
     launch_march_any(p, emit, fd, st);

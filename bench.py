@@ -9,16 +9,22 @@ A "step" is one lattice update (simStep, html:510-525) of the whole tunnel.  Wor
 BASELINE.json configs[2] — 4096x4096 fp32, AoA 10 deg, U0 0.06, tau 0.58.  The S1223 coordinates
 named there are not available offline (no network; the reference ships no .dat files), so the
 body is the reference's own high-camber built-in shape NACA 6409 (html:127); the kernel's cost
-depends on the body only through the fraction of wave-tiles that touch its surface.
+depends on the body only through the fraction of window-tiles that touch its surface.
 
 N > 1: the SAME 4096x4096 lattice is split into N column slabs (strong scaling, as the metric
 "MLUPS on 4096^2 ... at 1/2/4/8 MI355X" is quoted), one process per GPU, ghost columns
-exchanged by RCCL send/recv inside libwindtunnel every `halo` steps.
+exchanged by RCCL send/recv inside libwindtunnel every `halo` steps.  That path has never met more
+than one GPU (no multi-GPU box was available to the builder): every rank first runs the library's
+one-rank RCCL self-test, then joins the communicator under a watchdog; any failure prints rank,
+device and wt_last_error() and exits non-zero — nothing is retried and no process is re-exec'ed.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` and
-`cpu_baseline` objects.  The CPU baseline is the straight NumPy transcription of the scheme
-(oracle/lbm_numpy.py) timed on this host on a bounded sample — it is only ever the thing
-measured BESIDE the product, never part of it.
+`cpu_baseline` objects.  The roofline object carries BOTH views of the dominant kernel: the
+real HBM rate from the rocprofv3 counters (when profiles/pmc_traffic.json has an entry for this
+workload) and the "effective" rate at the scheme's 72 B per site update, which a pass
+that advances two steps can exceed because it moves fewer bytes.  The CPU baseline is the straight
+NumPy transcription of the scheme (oracle/lbm_numpy.py) timed on this host on a bounded sample — it
+is only ever the thing measured BESIDE the product, never part of it.
 """
 from __future__ import annotations
 
@@ -26,7 +32,12 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
+
+# the host driver of this pool only supports dmabuf IPC; without this RCCL / device-memory sharing across
+# processes fails with "hipIpcGetMemHandle: invalid argument" (set before anything loads the HIP runtime)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -35,6 +46,7 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s float4-copy)
 BYTES_PER_LUP = {"float32": 72, "float64": 144}   # 9 loads + 9 stores per site update
+COMM_TIMEOUT_S = 180.0
 
 
 def parse_args():
@@ -52,9 +64,9 @@ def parse_args():
     ap.add_argument("--halo", type=int, default=16, help="ghost columns per interior slab side (exchange every `halo` steps)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the NumPy CPU baseline (0 = skip)")
     ap.add_argument("--fuse", type=int, default=-1, choices=[-1, 0, 1, 2],
-                    help="two steps per pass over the lattice (csrc/step_fused.hpp; fp32; bit-identical): -1 library "
+                    help="two steps per pass over the lattice (csrc/step_march.hpp; fp32; bit-identical): -1 library "
                          "default (on where it pays for one GPU, off for slabs), 0 off, 1 where it pays, 2 always")
-    ap.add_argument("--fuse-chunk", type=int, default=0, help="columns per marching chunk (0 = chosen per mask)")
+    ap.add_argument("--fuse-chunk", type=int, default=0, help="cost limit of a marching unit in columns (0 = whole resident rounds)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -98,17 +110,62 @@ def baseline_metric():
         with open(os.path.join(ROOT, "BASELINE.json"), encoding="utf-8") as fh:
             return json.load(fh)["metric"]
     except Exception:
-        return "MLUPS on 4096\u00b2 fp32 D2Q9 at 1/2/4/8 MI355X; achieved % HBM3E peak"
+        return "MLUPS on 4096² fp32 D2Q9 at 1/2/4/8 MI355X; achieved % HBM3E peak"
 
 
 def measured_traffic(workload_key):
-    """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (None if absent)."""
+    """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (None if this workload was never profiled).
+    The entry was measured in ANOTHER run of this same command on another box of the pool; `source` says which."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            return json.load(fh).get(workload_key, {}).get("hbm_bytes_per_launch")
+            e = json.load(fh).get(workload_key)
     except Exception:
         return None
+    return e if e and "hbm_bytes_per_launch" in e else None
+
+
+def die(rank, device, what, err=None):
+    """One diagnosable line per failing rank, then a non-zero exit (never a retry, never a re-exec)."""
+    msg = f"[bench.py] rank {rank} (device {device}) FAILED: {what}"
+    if err is not None:
+        msg += f": {err}"
+    msg += ("  | re-run with NCCL_DEBUG=WARN (RCCL reads the NCCL_* variables) for the transport's own message; "
+            f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}")
+    print(msg, file=sys.stderr, flush=True)
+    os._exit(3)
+
+
+def with_watchdog(seconds, rank, device, what, fn):
+    """Runs fn(); if it has not returned after `seconds` the process reports and exits (a peer that never joins an
+    RCCL communicator would otherwise block this rank for ever)."""
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(seconds):
+            die(rank, device, f"{what} did not finish within {seconds:.0f} s (a peer is missing or the transport hangs)")
+
+    t = threading.Thread(target=watch, daemon=True)
+    t.start()
+    try:
+        return fn()
+    finally:
+        done.set()
+
+
+def roofline_entry(kernel, bytes_alg, launch_ms, traffic):
+    """Both views of one kernel: counter-based when profiles/pmc_traffic.json knows this workload, and the
+    'effective' rate at 72 (144) B per site update."""
+    eff = bytes_alg / (launch_ms * 1e-3) / 1e9
+    out = {"kernel": kernel, "launch_ms": launch_ms, "algorithmic_bytes_per_launch": bytes_alg,
+           "effective_gbps": eff, "effective_frac": eff / HBM_PEAK_GBPS,
+           "traffic": None, "traffic_source": None, "counter_gbps": None}
+    if traffic is not None:
+        t = float(traffic["hbm_bytes_per_launch"])
+        out["traffic"] = t
+        out["traffic_source"] = {k: traffic.get(k) for k in ("source", "measured", "kernel") if k in traffic}
+        out["counter_gbps"] = t / (launch_ms * 1e-3) / 1e9
+    return out
 
 
 def main():
@@ -118,9 +175,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+            print("bench.py --gpus N>1 must be launched with torch.distributed.run, one process per GPU:\n"
+                  "  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P "
+                  "bench.py --gpus N --steps K --warmup W", file=sys.stderr, flush=True)
+            raise SystemExit(2)
         args.gpus = world
 
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -128,65 +189,123 @@ def main():
 
     if os.environ.get("WT_BENCH_FORCE_DEVICE") is not None:      # plumbing tests on a 1-GPU box only
         local_rank = int(os.environ["WT_BENCH_FORCE_DEVICE"])
-    torch.cuda.set_device(local_rank)
     distributed = world > 1
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        die(rank, local_rank, f"LOCAL_RANK {local_rank} but only {ndev} HIP device(s) are visible")
+    torch.cuda.set_device(local_rank)
     if distributed:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # 1. this rank's own RCCL plumbing, before any peer is involved
+        try:
+            wtpkg.Engine.comm_selftest(local_rank, 1024)
+        except Exception as e:      # noqa: BLE001 - every failure is reported the same way
+            die(rank, local_rank, "wt_comm_selftest (one-rank RCCL send/recv on this GPU)", e)
+        try:
+            with_watchdog(COMM_TIMEOUT_S, rank, local_rank, "torch.distributed.init_process_group(nccl)",
+                          lambda: dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                                          timeout=datetime.timedelta(seconds=COMM_TIMEOUT_S)))
+        except Exception as e:      # noqa: BLE001
+            die(rank, local_rank, "torch.distributed.init_process_group(nccl)", e)
 
     nx_total = args.nx if (args.scaling == "strong" or world == 1) else args.nx * world
     ny = args.ny
     geom = wtpkg.geometry.build_geometry(nx_total, ny, args.aoa, None, args.shape)
     mask = geom.mask
 
-    if distributed:
-        eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank, rank=rank, nranks=world, halo=args.halo)
-        if args.fuse >= 0 and args.dtype == "float32":
-            eng.set_option("fuse_chunk", args.fuse_chunk)
-            eng.set_option("fuse_steps", args.fuse)
-        ids = [wtpkg.Engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init_rank(ids[0])
-    else:
-        eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank)
-        if args.fuse >= 0 and args.dtype == "float32":
-            eng.set_option("fuse_chunk", args.fuse_chunk)
-            eng.set_option("fuse_steps", args.fuse)
-    eng.set_mask(mask)
-    eng.init_equilibrium(args.u0)
+    try:
+        if distributed:
+            eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank, rank=rank, nranks=world, halo=args.halo)
+        else:
+            eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank)
+        if args.dtype == "float32":
+            if args.fuse_chunk > 0:
+                eng.set_option("fuse_chunk", args.fuse_chunk)
+            if args.fuse >= 0:
+                eng.set_option("fuse_steps", args.fuse)
+        if distributed:
+            # 2. the library's own communicator (beside torch's): unique id through torch.distributed, join under a watchdog
+            ids = [wtpkg.Engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            with_watchdog(COMM_TIMEOUT_S, rank, local_rank, "wt_comm_init_rank (ncclCommInitRank)", lambda: eng.comm_init_rank(ids[0]))
+        eng.set_mask(mask)
+        eng.init_equilibrium(args.u0)
+    except Exception as e:      # noqa: BLE001
+        die(rank, local_rank, "engine set-up", e)
 
     def barrier():
         if distributed:
             dist.barrier()
 
-    # warm-up (untimed)
-    if args.warmup > 0:
-        eng.step(args.warmup, args.tau, args.u0)
-    eng.sync()
-    torch.cuda.synchronize()
-    barrier()
+    try:
+        # warm-up (untimed); the first exchange of a slab run happens here
+        if args.warmup > 0:
+            with_watchdog(COMM_TIMEOUT_S, rank, local_rank, "warm-up steps", lambda: eng.step(args.warmup, args.tau, args.u0))
+        eng.sync()
+        torch.cuda.synchronize()
+        barrier()
 
-    # timed region: exactly K steps; HIP events on the library's compute stream give the device time
-    t0 = time.perf_counter()
-    dev_ms = eng.step_timed(args.steps, args.tau, args.u0)
-    eng.sync()
-    torch.cuda.synchronize()
-    barrier()
-    wall = time.perf_counter() - t0
+        # timed region: exactly K steps; HIP events on the library's compute stream give the device time
+        t0 = time.perf_counter()
+        dev_ms = eng.step_timed(args.steps, args.tau, args.u0)
+        eng.sync()
+        torch.cuda.synchronize()
+        barrier()
+        wall = time.perf_counter() - t0
+    except Exception as e:      # noqa: BLE001
+        die(rank, local_rank, "stepping", e)
 
+    per_rank_ms = [dev_ms]
     if distributed:
         t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([dev_ms], dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank_ms = [float(g[0]) for g in gathered]
         wall, dev_ms = float(t[0]), float(t[1])
 
     sites = nx_total * ny
     mlups = sites * args.steps / wall / 1e6
     bpl = BYTES_PER_LUP[args.dtype]
     fused = bool(eng.get_option("fuse_active"))
-    launch_ms = dev_ms / args.steps                      # one step = one launch of k_step over the slab
-    if fused:
-        launch_ms *= 2.0                                 # one pass (k_step2 + the two list passes) = TWO steps
+    steps_per_launch = 2 if fused else 1
+    launch_ms = dev_ms / args.steps * steps_per_launch     # one launch = one pass of the dominant kernel over the slab
     sites_per_launch = eng.width * ny if not distributed else (nx_total // world) * ny
-    achieved = bpl * sites_per_launch * (2 if fused else 1) / (launch_ms * 1e-3) / 1e9
+    key = f"{nx_total}x{ny}_{args.dtype}"
+    main_kernel = ("wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_rows per pass)" if fused else "wt::k_step")
+    traffic = None if distributed else measured_traffic(key + ("_march" if fused else ""))
+    r = roofline_entry(main_kernel, bpl * sites_per_launch * steps_per_launch, launch_ms, traffic)
+    # `achieved` is the REAL HBM rate (counters) when this workload has been profiled, else the effective rate
+    basis = "counters" if r["counter_gbps"] is not None else "effective"
+    achieved = r["counter_gbps"] if r["counter_gbps"] is not None else r["effective_gbps"]
+    cfg_fuse = {"fuse_steps": int(fused), "fuse_chunk": int(eng.get_option("fuse_chunk")) if fused else 0,
+                "fuse_units": int(eng.get_option("fuse_units")) if fused else 0,
+                "fast_div": int(eng.get_option("fast_div_active")) if fused else 0}
+    roofline = {"bound": "hbm", "kernel": main_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "achieved_basis": ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/pmc_traffic.json) / this run's launch time"
+                                   if basis == "counters" else
+                                   f"effective: {bpl} B per site update x sites x steps per launch / launch time"
+                                   + (" (a two-step pass moves fewer bytes than that; no counter entry for this workload)" if fused else "")),
+                "traffic": r["traffic"], "traffic_source": r["traffic_source"], "counter_gbps": r["counter_gbps"],
+                "effective_gbps": r["effective_gbps"], "effective_frac": r["effective_frac"],
+                "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "launch_ms": launch_ms,
+                "steps_per_launch": steps_per_launch}
+    if fused and not distributed:
+        # the un-fused kernel beside it, same run, same lattice state
+        try:
+            eng.set_option("fuse_steps", 0)
+            eng.step(4, args.tau, args.u0)
+            n1 = max(10, min(40, args.steps))
+            ms1 = eng.step_timed(n1, args.tau, args.u0) / n1
+            s = roofline_entry("wt::k_step (one step per launch)", bpl * sites_per_launch, ms1, measured_traffic(key))
+            s["achieved"] = s["counter_gbps"] if s["counter_gbps"] is not None else s["effective_gbps"]
+            s["frac"] = s["achieved"] / HBM_PEAK_GBPS
+            s["mlups"] = sites / (ms1 * 1e-3) / 1e6
+            roofline["single_step"] = s
+        except Exception as e:      # noqa: BLE001
+            roofline["single_step"] = {"error": str(e)}
+
     workload = (f"{args.shape.upper()} {nx_total}x{ny} {args.dtype} D2Q9, AoA={args.aoa:g} deg, U0={args.u0:g}, "
                 f"tau={args.tau:g} (BASELINE configs[2]; S1223 coordinates unavailable offline -> NACA 6409)")
     out = {
@@ -203,20 +322,10 @@ def main():
         "dtype": "f32" if args.dtype == "float32" else "f64",
         "data": "synthetic",
         "config": {"workload": workload, "nx": nx_total, "ny": ny, "slabs": world,
-                   "halo": args.halo if distributed else 0, "fuse_steps": int(fused),
-                   "fuse_chunk": int(eng.get_option("fuse_chunk")) if fused else 0,
+                   "halo": args.halo if distributed else 0, **cfg_fuse,
                    "solid_sites": int((mask != 0).sum())},
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "wt::k_step2 (+ k_step_list x2 on the body zone), two steps per pass" if fused else "wt::k_step",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": measured_traffic(f"{nx_total}x{ny}_{args.dtype}" + ("_fused" if fused else "")) if not distributed else None,
-            "algorithmic_bytes_per_launch": bpl * sites_per_launch * (2 if fused else 1),
-            "launch_ms": launch_ms,
-        },
+        "device_ms": per_rank_ms,
+        "roofline": roofline,
     }
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(mask, args.cpu_steps, args.tau, args.u0, args.dtype)

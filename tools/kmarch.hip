@@ -161,9 +161,9 @@ static void march_pass(const Lattice &L, const DevPlan &d, const float *a, float
 {
     const float rtau = 1.0f / tau;
     if (L.nwin > 1) {
-        const long nth = (long)(L.nwin - 1) * 2 * L.g.nxl;
+        const long nth = (long)(L.nwin - 1) * L.g.nxl;
         const FastDiv fdv{tau, rtau};
-        hipLaunchKernelGGL((k_halo_rows<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, L.halo, L.g, L.nwin, fdv, U0);
+        hipLaunchKernelGGL((k_halo_rows<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.bcode, L.halo, L.g, L.nwin, fdv, U0);
     }
     if (sb != st) { CK(hipEventRecord(ev0, st)); CK(hipStreamWaitEvent(sb, ev0, 0)); }
     if (d.nbody) hipLaunchKernelGGL((k_march<true, EMIT, FD, WB, PF>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), g_lds_bytes, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
@@ -262,7 +262,8 @@ int main(int argc, char **argv)
     std::vector<Var> vs;
     std::vector<DevPlan> plans; plans.reserve(256);
     vs.push_back({"k_step x2 (production)", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(L.f1, b, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
-    for (long U : {2048L, 4096L, 6144L, 8192L}) {
+    vs.push_back({"k_halo_rows only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.bcode, L.halo, L.g, L.nwin, fdv, U0); }, {}, 1});
+    for (long U : {2048L, 4096L}) {
         plans.push_back(upload_plan(L0, U)); DevPlan *d0 = &plans.back();
         vs.push_back({"nobody, target " + std::to_string(U) + " units (" + std::to_string(d0->nbody) + ")", [&, d0](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
         for (double alpha : {0.5, 1.0, 2.0}) {
