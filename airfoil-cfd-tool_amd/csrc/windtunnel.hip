@@ -84,6 +84,7 @@ struct wt_handle {
     hipStream_t s_compute = nullptr, s_comm = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_state = nullptr, ev_halo = nullptr;
     bool mask_set = false, inited = false;
+    bool macro_stale = false;    // wt_write_f replaced the populations: (rho,ux,uy) describe an older state until a step emits them
     int ghost_valid = 0;         // ghost columns still exact (both sides)
     long long steps_done = 0;
     long long device_bytes = 0;
@@ -484,6 +485,7 @@ extern "C" int wt_init_equilibrium(wt_handle *h, double u0)
     WT_TRY(h->dtype == WT_F32 ? init_impl<float>(h, u0) : init_impl<double>(h, u0));
     h->cur = 0;
     h->inited = true;
+    h->macro_stale = false;
     h->steps_done = 0;
     h->ghost_valid = h->halo;     // a uniform state is exact everywhere, ghosts included
     return WT_OK;
@@ -700,6 +702,7 @@ static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
             s += 1;
         }
     }
+    if (nsteps > 0) h->macro_stale = false;     // the last step emitted (rho,ux,uy)
     return WT_OK;
 }
 
@@ -763,7 +766,7 @@ extern "C" int wt_comm_selftest(int device, int ny)
     ncclUniqueId id;
     NCCL_TRY(ncclGetUniqueId(&id));
     ncclComm_t comm = nullptr;
-    NCCL_TRY(ncclCommInitRank(&comm, 1, id, 0));
+    NCCL_TRY(ncclCommInitRank(&comm, 1, id, 0));   // (nothing to release before this point)
     const size_t count = (size_t)ny * 16;          // 16 ghost columns
     float *src = nullptr, *dst = nullptr;
     hipStream_t st = nullptr;
@@ -882,6 +885,7 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
         }
         s += 1;
     }
+    if (nsteps > 0) for (int r = 0; r < n; r++) hs[r]->macro_stale = false;
     return WT_OK;
 }
 
@@ -950,6 +954,7 @@ extern "C" int wt_write_f(wt_handle *h, const void *f_in)
     }
     WT_TRY(h->dtype == WT_F32 ? write_f_impl<float>(h, f_in) : write_f_impl<double>(h, f_in));
     h->inited = true;
+    h->macro_stale = true;   // the macro planes still hold the previous state's (rho,ux,uy)
     h->ghost_valid = 0;      // ghosts must be refreshed from the neighbours before the next step
     h->steps_done = 0;
     return WT_OK;
@@ -973,6 +978,7 @@ extern "C" int wt_read_macro(wt_handle *h, void *rho, void *ux, void *uy)
 {
     WT_TRY(check_handle(h));
     if (!h->inited) return fail(WT_ERR_STATE, "no state to read");
+    if (h->macro_stale) return fail(WT_ERR_STATE, "wt_write_f replaced the populations: (rho,ux,uy) are emitted by the next wt_step");
     HIP_TRY(hipSetDevice(h->device));
     return h->dtype == WT_F32 ? read_macro_impl<float>(h, rho, ux, uy) : read_macro_impl<double>(h, rho, ux, uy);
 }
@@ -982,6 +988,7 @@ extern "C" int wt_reduce_ranges(wt_handle *h, double u0, double *max_s, double *
     WT_TRY(check_handle(h));
     if (!max_s || !cp_min || !cp_max) return fail(WT_ERR_ARG, "null output");
     if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (h->macro_stale) return fail(WT_ERR_STATE, "wt_write_f replaced the populations: (rho,ux,uy) are emitted by the next wt_step");
     if (!(u0 != 0.0)) return fail(WT_ERR_ARG, "u0 must be non-zero");
     HIP_TRY(hipSetDevice(h->device));
     const long total = (long)h->width * h->g.ny;
@@ -1013,6 +1020,7 @@ extern "C" int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, in
     WT_TRY(check_handle(h));
     if (!fx || !fy || !surf || !rev) return fail(WT_ERR_ARG, "null output");
     if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (h->macro_stale) return fail(WT_ERR_STATE, "wt_write_f replaced the populations: (rho,ux,uy) are emitted by the next wt_step");
     HIP_TRY(hipSetDevice(h->device));
     const long total = (long)h->width * h->g.ny;
     int nb = (int)((total + 255) / 256);
@@ -1049,16 +1057,18 @@ static int refresh_macro_ghosts(wt_handle *h)
     if (h->transport == TR_RCCL) {
         const ncclDataType_t dt = h->dtype == WT_F32 ? ncclFloat32 : ncclFloat64;
         const size_t count = (size_t)g.pitch;
-        NCCL_TRY(ncclGroupStart());
-        if (h->gl) {
-            NCCL_TRY(ncclSend(uy_col(h, h->gl), count, dt, h->rank - 1, h->comm, h->s_comm));
-            NCCL_TRY(ncclRecv(uy_col(h, h->gl - 1), count, dt, h->rank - 1, h->comm, h->s_comm));
+        ncclResult_t rc = ncclGroupStart();
+        if (h->gl && rc == ncclSuccess) {
+            rc = ncclSend(uy_col(h, h->gl), count, dt, h->rank - 1, h->comm, h->s_comm);
+            if (rc == ncclSuccess) rc = ncclRecv(uy_col(h, h->gl - 1), count, dt, h->rank - 1, h->comm, h->s_comm);
         }
-        if (h->gr) {
-            NCCL_TRY(ncclSend(uy_col(h, h->gl + h->width - 1), count, dt, h->rank + 1, h->comm, h->s_comm));
-            NCCL_TRY(ncclRecv(uy_col(h, h->gl + h->width), count, dt, h->rank + 1, h->comm, h->s_comm));
+        if (h->gr && rc == ncclSuccess) {
+            rc = ncclSend(uy_col(h, h->gl + h->width - 1), count, dt, h->rank + 1, h->comm, h->s_comm);
+            if (rc == ncclSuccess) rc = ncclRecv(uy_col(h, h->gl + h->width), count, dt, h->rank + 1, h->comm, h->s_comm);
         }
-        NCCL_TRY(ncclGroupEnd());
+        const ncclResult_t rc_end = ncclGroupEnd();            // always close the group, even after a failure
+        if (rc == ncclSuccess) rc = rc_end;
+        if (rc != ncclSuccess) return fail(WT_ERR_RCCL, "macro ghost-column exchange failed: %s", ncclGetErrorString(rc));
     } else {
         const size_t bytes = (size_t)g.pitch * h->esz;
         if (h->gl) {
@@ -1100,6 +1110,7 @@ extern "C" int wt_field(wt_handle *h, int mode, double u0, double max_s, double 
     if (!t_out) return fail(WT_ERR_ARG, "t_out is null");
     if (mode < 0 || mode > 2) return fail(WT_ERR_ARG, "mode must be 0 (speed), 1 (cp) or 2 (vort)");
     if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (h->macro_stale) return fail(WT_ERR_STATE, "wt_write_f replaced the populations: (rho,ux,uy) are emitted by the next wt_step");
     HIP_TRY(hipSetDevice(h->device));
     if (mode == WT_FIELD_VORT && h->nranks > 1) WT_TRY(refresh_macro_ghosts(h));
     return h->dtype == WT_F32 ? field_impl<float>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, t_out)
@@ -1130,6 +1141,7 @@ extern "C" int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, d
     if (!rgba_out) return fail(WT_ERR_ARG, "rgba_out is null");
     if (mode < 0 || mode > 2) return fail(WT_ERR_ARG, "mode must be 0 (speed), 1 (cp) or 2 (vort)");
     if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (h->macro_stale) return fail(WT_ERR_STATE, "wt_write_f replaced the populations: (rho,ux,uy) are emitted by the next wt_step");
     HIP_TRY(hipSetDevice(h->device));
     if (mode == WT_FIELD_VORT && h->nranks > 1) WT_TRY(refresh_macro_ghosts(h));
     return h->dtype == WT_F32 ? render_impl<float>(h, mode, u0, max_s, cp_min, cp_max, vort_scale, rgba_out)
@@ -1146,6 +1158,7 @@ extern "C" int wt_advect_tracers(wt_handle *h, int n, const double *x, const dou
     WT_TRY(check_handle(h));
     if (n < 0 || (n > 0 && (!x || !y || !x_new || !y_new || !speed || !ok))) return fail(WT_ERR_ARG, "bad tracer arrays");
     if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (h->macro_stale) return fail(WT_ERR_STATE, "wt_write_f replaced the populations: (rho,ux,uy) are emitted by the next wt_step");
     if (h->nranks > 1) return fail(WT_ERR_STATE, "tracers need the whole lattice on one handle");
     if (!(dx1 > dx0) || !(dy1 > dy0) || !(u0 != 0.0)) return fail(WT_ERR_ARG, "bad window or u0");
     if (n == 0) return WT_OK;

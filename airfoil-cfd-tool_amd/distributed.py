@@ -50,6 +50,12 @@ class SlabWindTunnel(WindTunnel):
         self._engine_factory = engine_factory
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = int(device)
+        if dist.get_backend(group) == "nccl":
+            # collectives of this class run on THIS rank's GPU whatever thread calls them and whether or not the
+            # engine (whose hipSetDevice would otherwise be what selects the device) exists yet
+            import torch
+            torch.cuda.set_device(self.device)
         super().__init__(coords, name, nx=nx, ny=ny, device=device, **kwargs)
 
     # ---- hooks -------------------------------------------------------------------------
@@ -83,7 +89,7 @@ class SlabWindTunnel(WindTunnel):
 
     def _tensor_device(self):
         import torch
-        return torch.device("cuda") if self._dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        return torch.device("cuda", self.device) if self._dist.get_backend(self.group) == "nccl" else torch.device("cpu")
 
     def _all_reduce(self, values, op):
         import torch

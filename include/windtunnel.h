@@ -82,11 +82,16 @@ int wt_get_info(const wt_handle *h, wt_info *info);
 const char *wt_last_error(void);
 const char *wt_version(void);
 
-/* Tuning knobs (no counterpart in the reference).  "fuse_steps" (0 / 1 = where it pays / 2 = always): advance TWO steps per pass
- * over the lattice where the flow is plain (temporal fusion in registers, csrc/step_fused.hpp);
- * results are bit-identical either way.  fp32 handles (whole lattices and slabs) with NY % 4 == 0.  Default: 1
- * for whole-lattice handles, 0 for slab handles (environment WT_FUSE2=0|1|2 overrides at wt_create).  "fuse_chunk": columns per marching chunk.
- * wt_get_option also reports "fuse_active", "fuse_units", "fuse_tiles_single". */
+/* Tuning knobs (no counterpart in the reference).
+ *   "fuse_steps" (0 / 1 = where it pays / 2 = always): advance TWO steps per pass over the lattice — a marching kernel
+ *       that keeps the intermediate step in registers, body / inlet / outlet included (csrc/step_march.hpp); results are
+ *       bit-identical either way.  fp32 handles (whole lattices and slabs) with NY % 4 == 0 and a lattice below 4 GiB.
+ *       Default: 1 for whole-lattice handles, 0 for slab handles (environment WT_FUSE2=0|1|2 overrides at wt_create).
+ *   "fuse_chunk": cost limit of one marching unit in columns (0 = whole resident rounds of units, the default).
+ *   "fast_div" (default 1): divide by tau through a reciprocal and two fused multiply-adds where an exhaustive
+ *       on-device check over all 2^23 significands has PROVED the sequence equal to the IEEE quotient for this tau
+ *       (csrc/d2q9.hpp); 0 keeps the IEEE division everywhere.  Bit-identical either way.
+ * wt_get_option also reports "fuse_active", "fuse_units", "fuse_tiles_general", "fast_div_active". */
 int wt_set_option(wt_handle *h, const char *name, double value);
 int wt_get_option(const wt_handle *h, const char *name, double *value);
 
@@ -133,7 +138,12 @@ int wt_step(wt_handle *h, int nsteps, double tau, double u0);
  * blocks, and returns the elapsed device time in milliseconds. */
 int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, float *elapsed_ms);
 
-/* Test / checkpoint access to the populations, [9][NY][W]. */
+/* Test / checkpoint access to the populations, [9][NY][W].
+ * wt_write_f replaces the populations only: the (rho,ux,uy) planes the reference keeps in texC are the pre-collision
+ * moments of the step that PRODUCED a state (html:357-359) and cannot be derived from a restored state alone, so after
+ * wt_write_f the calls that read them (wt_read_macro, wt_reduce_ranges, wt_forces, wt_field, wt_render_rgba,
+ * wt_advect_tracers) return WT_ERR_STATE until a wt_step / wt_step_group with nsteps >= 1 has emitted them again.
+ * Slab handles: ghost columns are refreshed from the neighbours before the next step. */
 int wt_read_f(wt_handle *h, void *f_out);
 int wt_write_f(wt_handle *h, const void *f_in);
 

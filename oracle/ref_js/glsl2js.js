@@ -399,7 +399,7 @@ function makeRuntime(mode) {
     const o = (iy * s.w + ix) * s.ch;
     const d = s.data;
     if (s.ch === 4) return [d[o], d[o + 1], d[o + 2], d[o + 3]];
-    return [d[o] * s.scale, 0, 0, 1];
+    return [fr(d[o] * s.scale), 0, 0, 1];   // unsigned normalized: c / 255, then the nearest float
   }
   return { fr, V, tex };
 }

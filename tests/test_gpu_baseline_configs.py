@@ -69,6 +69,59 @@ def test_config3_16384x4096_slabs_vs_single_and_oracle(pkg, oracle_c):
             e.close()
 
 
+def test_config3_16384x4096_slabs_through_two_refresh_cycles(pkg):
+    """configs[3] at full size, halo 16, 2*halo + 2 steps: every one of the 8 in-process slabs refreshes its ghost
+    columns twice (exchange on the second stream beside the interior columns, edge strips behind the event) and the
+    result equals the single lattice bit for bit — single-step kernels on the slabs, then the marching kernel too."""
+    nx, ny, halo = 16384, 4096, 16
+    steps = 2 * halo + 2
+    mask = pkg.geometry.build_geometry(nx, ny, 8.0, None, "naca0012").mask
+    assert int((mask != 0).sum()) == 3232941                                 # SURVEY §8c
+    f, m = _gpu(pkg, mask, steps, 0.58, 0.06, "float32")
+    for fuse in (0, 2):
+        es = [pkg.Engine(nx, ny, rank=r, nranks=8, halo=halo) for r in range(8)]
+        try:
+            pkg.Engine.link_local(es)
+            for e in es:
+                e.set_option("fuse_steps", fuse)
+                e.set_mask(mask); e.init_equilibrium(0.06)
+            if fuse:
+                assert all(e.get_option("fuse_active") == 1.0 for e in es)
+            pkg.Engine.step_group(es, steps, 0.58, 0.06)
+            for e in es:
+                assert e.info().steps_done == steps
+                assert bits_equal(e.read_f(), np.ascontiguousarray(f[:, :, e.x0:e.x0 + e.width]))
+                assert all(bits_equal(a, np.ascontiguousarray(b[:, e.x0:e.x0 + e.width])) for a, b in zip(e.read_macro(), m))
+        finally:
+            for e in es:
+                e.close()
+
+
+def test_config4_full_size_stall_label_and_vorticity_sign(pkg, oracle_c, oracle_np):
+    """configs[4] at FULL size (4096x2048 fp64, NACA 4412, 12 deg, Re 1e6 -> tau ~ 0.5004): 20 frames of 12 steps with
+    the force read-out after each (html:650-700), then the stall label (html:862-885) and the sign structure of the
+    vorticity field (html:411-417) against the C oracle run in lock step; populations bit-identical at the end."""
+    nx, ny = 4096, 2048
+    tau = pkg.tau_from_reynolds(1e6, 0.06, nx)
+    with pkg.WindTunnel(shape="naca4412", nx=nx, ny=ny, aoa_deg=12.0, tau=tau, dtype="float64") as wt:
+        assert int((wt.geometry.mask != 0).sum()) == 405515
+        st = oracle_np.ForceState()
+        f = None
+        for _ in range(20):
+            wt.sim_step(12)
+            wt.compute_forces()
+            f, mac = oracle_c.run(wt.geometry.mask, 12, tau, 0.06, np.float64, f=f)
+            st.update(*oracle_np.compute_forces_raw(mac[0], mac[1], wt.geometry.mask), 0.06, nx)
+        assert wt.stats().separation == oracle_np.stall_label(st.sep)
+        np.testing.assert_allclose([wt.cl_smooth, wt.cd_smooth, wt.sep_frac], [st.cl, st.cd, st.sep], rtol=1e-9, atol=1e-12)
+        assert bits_equal(wt.read_f(), f)
+        wt.update_fields_from_macro()
+        t = wt.render_field(field="vort")
+        ref = oracle_np.field_scalar(2, *mac, wt.geometry.mask, 0.06, wt.max_s, wt.cp_min, wt.cp_max)
+        assert np.array_equal(np.sign(np.nan_to_num(t)), np.sign(np.nan_to_num(ref)))
+        assert np.array_equal(np.isnan(t), wt.geometry.mask != 0)
+
+
 def test_low_tau_fp64_stall_indicator_matches_oracle(pkg, oracle_c, oracle_np):
     """configs[4] in miniature (fp64, Re-derived tau ~0.5004, 12 deg): separation label and
     vorticity sign structure — identical because the fields are bit-identical."""

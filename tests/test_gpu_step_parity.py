@@ -108,10 +108,15 @@ def test_write_f_read_f_roundtrip_and_restart(pkg, oracle_c):
         e.set_mask(mask)
         e.write_f(f0)
         assert bits_equal(e.read_f(), f0)
+        # (rho,ux,uy) belong to the step that produced a state: after a restore they are unavailable until a step emits them
+        for call in (e.read_macro, lambda: e.reduce_ranges(0.05), e.forces, lambda: e.field(0, 0.05, 1.0, -1.0, 1.0, 0.06)):
+            with pytest.raises(pkg.WTError) as err:
+                call()
+            assert err.value.code == -5 and "wt_write_f" in str(err.value)
         e.step(25, 0.6, 0.05)
-        f = e.read_f()
-    f_ref, _ = oracle_c.run(mask, 25, 0.6, 0.05, np.float32, f=f0)
-    assert bits_equal(f, f_ref)
+        f, m = e.read_f(), e.read_macro()
+    f_ref, m_ref = oracle_c.run(mask, 25, 0.6, 0.05, np.float32, f=f0)
+    assert bits_equal(f, f_ref) and all(bits_equal(a, b) for a, b in zip(m, m_ref))
 
 
 def test_geometry_change_keeps_flow_state(pkg, oracle_c):
