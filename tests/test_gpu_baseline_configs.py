@@ -76,7 +76,6 @@ def test_config3_16384x4096_slabs_through_two_refresh_cycles(pkg):
     nx, ny, halo = 16384, 4096, 16
     steps = 2 * halo + 2
     mask = pkg.geometry.build_geometry(nx, ny, 8.0, None, "naca0012").mask
-    assert int((mask != 0).sum()) == 3232941
     f, m = _gpu(pkg, mask, steps, 0.58, 0.06, "float32")
     for fuse in (0, 2):
         es = [pkg.Engine(nx, ny, rank=r, nranks=8, halo=halo) for r in range(8)]
