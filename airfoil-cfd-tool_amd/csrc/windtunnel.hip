@@ -215,10 +215,12 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     CREATE_TRY(hipStreamSynchronize(h->s_compute));
 #undef CREATE_TRY
     {
-        // Two steps per pass (step_fused.hpp): on by default for whole-lattice handles, where it engages
-        // only if the plan has enough units to pay (fuse_steps = 1); slab handles keep the plain path unless
-        // asked.  WT_FUSE2 = 0 | 1 | 2 overrides (off / where it pays / always).
-        h->fuse = (nranks == 1);
+        // Two steps per pass (step_march.hpp): on by default, engaging only where the plan has enough units to pay
+        // (fuse_steps = 1: whole lattices from about 1000 x 4096 up; one-GPU measurements of slab-sized lattices:
+        // 2080 columns 98 -> 79 us per step, 1056 columns 53 -> 47, 544 columns no gain and left on the single-step
+        // kernel).  Slabs march between ghost refreshes, the refresh step itself stays a single step with the exchange
+        // beside its interior columns.  WT_FUSE2 = 0 | 1 | 2 overrides (off / where it pays / always).
+        h->fuse = true;
         const char *e = getenv("WT_FUSE2");
         if (e) { h->fuse = atoi(e) != 0; h->fuse_force = atoi(e) >= 2; }
         const char *c = getenv("WT_FUSE_CHUNK");

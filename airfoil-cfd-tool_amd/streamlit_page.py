@@ -4,7 +4,10 @@
 (call sites AA.py:1210-1213, 1413-1416, captions AA.py:1397-1432).  This module keeps that
 function's name and inputs and renders the MI355X tunnel instead: the component's own controls
 (html:20-58: angle of attack, field, flow speed, trails), the read-outs of html:53-57 (CL, CD,
-Reynolds, separation) and the field image; one rerun of the script = a batch of frames.
+Reynolds, separation) and the composited canvas (compose.py).  Like the page's requestAnimationFrame
+loop (html:902-930) the image keeps advancing WITHOUT a user action: one call streams `frames` canvas
+updates into an ``st.empty()`` placeholder (and the four read-outs into theirs), `frames_per_update`
+simulation frames apart; a widget change reruns the script, which picks the same tunnel up again.
 
 ``streamlit`` is imported lazily (it is not installed in the build image); everything else is the
 package's ordinary host API, so a page needs only::
@@ -18,6 +21,7 @@ from typing import Optional
 
 import numpy as np
 
+from .compose import TrailLayer
 from .tracers import Tracers
 from .windtunnel import WindTunnel
 
@@ -34,13 +38,15 @@ def _tunnel_for(st, coords_after, airfoil_name: str, nx: int, ny: int, dtype: st
             old.close()
         store["wt_amd_tunnel"] = WindTunnel(coords_after, airfoil_name, nx=nx, ny=ny, dtype=dtype)
         store["wt_amd_tracers"] = None
+        store["wt_amd_trails"] = None
         store["wt_amd_key"] = key
     return store["wt_amd_tunnel"]
 
 
 def build_lbm_component(coords_after, airfoil_name: str = "", *, nx: int = 1024, ny: int = 512,
-                        dtype: str = "float32", frames_per_rerun: int = 15, st=None) -> Optional[WindTunnel]:
-    """Render the interactive LBM wind tunnel for the user's parsed coordinates (AA.py:20-42)."""
+                        dtype: str = "float32", frames: int = 240, frames_per_update: int = 4, scale: int = 1,
+                        st=None) -> Optional[WindTunnel]:
+    """Render the interactive LBM wind tunnel for the user's parsed coordinates (AA.py:20-42) and stream it live."""
     if st is None:
         import streamlit as st          # noqa: PLC0415  (lazy: absent in the build image)
     try:
@@ -63,20 +69,29 @@ def build_lbm_component(coords_after, airfoil_name: str = "", *, nx: int = 1024,
         tracers = st.session_state["wt_amd_tracers"] = Tracers(wt, n=ntrails)
     elif tracers.x.size != ntrails:
         tracers.resize(ntrails)
+    layer = st.session_state.get("wt_amd_trails")
+    if layer is None or layer.s != scale:
+        layer = st.session_state["wt_amd_trails"] = TrailLayer(scale)
 
-    segments = []
-    for _ in range(int(frames_per_rerun)):
-        wt.frame(render=False)                                                       # html:902-915
-        segments.append(tracers.step(16.0))                                          # html:917
-    image = wt.render_rgba()[::-1]                                                   # top row first for display
-
-    st.image(np.ascontiguousarray(image), caption="D2Q9 lattice-Boltzmann · MI355X · live unsteady solve",
-             use_column_width=True)
-    s = wt.stats()
+    canvas = st.empty()                                                              # the <canvas> of the component
     c1, c2, c3, c4 = st.columns(4)
-    c1.metric("CL (approx)", "—" if s.cl is None else f"{s.cl:.3f}")                 # html:863
-    c2.metric("CD (approx)", "—" if s.cd is None else f"{s.cd:.3f}")                 # html:864
-    c3.metric("Reynolds", f"{round(s.reynolds):,}")                                   # html:865-866
-    c4.metric("Separation", s.separation)                                            # html:869-884
-    st.session_state["wt_amd_segments"] = segments[-1]
+    slots = [c.empty() for c in (c1, c2, c3, c4)]
+
+    def show():
+        canvas.image(wt.compose_frame(trails=layer, scale=scale), caption="D2Q9 lattice-Boltzmann · MI355X · live unsteady solve",
+                     use_column_width=True)
+        s = wt.stats()                                                               # updateStatsUI, html:862-885
+        slots[0].metric("CL (approx)", "—" if s.cl is None else f"{s.cl:.3f}")
+        slots[1].metric("CD (approx)", "—" if s.cd is None else f"{s.cd:.3f}")
+        slots[2].metric("Reynolds", f"{round(s.reynolds):,}")
+        slots[3].metric("Separation", s.separation)
+
+    done = 0
+    while done < int(frames):                                                        # the rAF loop, html:902-930
+        for _ in range(max(1, int(frames_per_update))):
+            wt.frame(render=False)                                                   # 4 steps, ranges, forces every 3rd frame
+            tracers.draw(layer, 16.0)                                                # stepParticles(dt), html:917
+            done += 1
+        show()
+    st.session_state["wt_amd_frames"] = st.session_state.get("wt_amd_frames", 0) + done
     return wt

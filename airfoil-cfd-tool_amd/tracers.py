@@ -5,8 +5,9 @@ Host side of the reference's particle system, ``pages/airfoil_flow_lbm_aerolab.h
 drain, respawn).  The deterministic part — ``advect`` 758-771 over ``sampleUV`` 616-639 — runs
 on the GPU (``wt_advect_tracers``).  The reference seeds with ``Math.random``; here a NumPy
 ``Generator`` takes its place, so only the deterministic part has exact goldens and the seeding
-is compared statistically.  Canvas stroking is browser work: ``step`` returns the
-segments and colours instead of drawing them.
+is compared statistically.  ``step`` returns the segments and their colour-map
+arguments; ``draw`` strokes them onto a fading ``compose.TrailLayer`` the way html:781-803 strokes the
+particle canvas.
 """
 from __future__ import annotations
 
@@ -70,6 +71,14 @@ class Tracers:
             x, y, life = self._spawn(np.zeros(n - cur, bool), lane)
             self.x, self.y = np.concatenate([self.x, x]), np.concatenate([self.y, y])
             self.life, self.lane = np.concatenate([self.life, life]), np.concatenate([self.lane, lane])
+
+    def draw(self, layer, dt: float = 16.0):
+        """stepParticles(dt) including the drawing (html:780-808): fade the layer, advance, stroke the moved particles."""
+        from .compose import Canvas
+        seg, t = self.step(dt)
+        layer.fade()
+        layer.stroke(Canvas(layer.s), seg, t, self.window[3])
+        return seg, t
 
     # html:780-808
     def step(self, dt: float = 16.0):

@@ -210,11 +210,28 @@ class WindTunnel:
         mode = FIELD_MODES[field or self.field]
         return self.engine.render_rgba(mode, self.u0, self.max_s, self.cp_min, self.cp_max, VORT_SCALE)
 
-    def save_png(self, path: Optional[str] = None, field: Optional[str] = None) -> str:
-        """The field image as a PNG named like the page's download (html:980-1000).  Only the
-        lattice field is drawn (the page's particles/labels are browser-side canvas work)."""
+    def y_half_world(self) -> float:
+        """Half-height of the tunnel window in chord units (html:73 on 2:1 lattices; square cells otherwise)."""
+        return self.y_half if self.y_half is not None else geo.domain_y_half(self.nx, self.ny)
+
+    def compose_frame(self, field: Optional[str] = None, trails=None, scale: int = 1) -> np.ndarray:
+        """The page's whole canvas for the current state (html:919-927): field image scaled into the plot rectangle,
+        tracer strokes (a compose.TrailLayer, see tracers.Tracers.draw), foil fill + outline, colour bar with captions,
+        axis ticks and the angle read-out.  RGBA8 [360*scale][680*scale][4], top row first."""
+        from . import compose
+        mode = FIELD_MODES[field or self.field]
+        return compose.compose(self.render_rgba(field)[::-1], self.geometry.xp, self.geometry.yp, self.aoa_deg, mode,
+                               self.y_half_world(), trails=trails, scale=scale)
+
+    def save_png(self, path: Optional[str] = None, field: Optional[str] = None, composite: bool = True, trails=None,
+                 scale: int = 1) -> str:
+        """The PNG button (html:980-1000): the composited canvas under the page's file name; composite=False writes the
+        bare lattice field at lattice resolution instead."""
         path = path or self.png_name()
-        write_png(path, self.render_rgba(field)[::-1])          # PNG rows run top to bottom
+        if composite:
+            write_png(path, self.compose_frame(field, trails=trails, scale=scale))
+        else:
+            write_png(path, self.render_rgba(field)[::-1])      # PNG rows run top to bottom
         return path
 
     def frame(self, render: bool = True):

@@ -86,7 +86,7 @@ const char *wt_version(void);
  *   "fuse_steps" (0 / 1 = where it pays / 2 = always): advance TWO steps per pass over the lattice — a marching kernel
  *       that keeps the intermediate step in registers, body / inlet / outlet included (csrc/step_march.hpp); results are
  *       bit-identical either way.  fp32 handles (whole lattices and slabs) with NY % 4 == 0 and a lattice below 4 GiB.
- *       Default: 1 for whole-lattice handles, 0 for slab handles (environment WT_FUSE2=0|1|2 overrides at wt_create).
+ *       Default: 1 (environment WT_FUSE2=0|1|2 overrides at wt_create); handles that are not eligible stay on the single-step kernel.
  *   "fuse_chunk": cost limit of one marching unit in columns (0 = whole resident rounds of units, the default).
  *   "fast_div" (default 1): divide by tau through a reciprocal and two fused multiply-adds where an exhaustive
  *       on-device check over all 2^23 significands has PROVED the sequence equal to the IEEE quotient for this tau

@@ -65,31 +65,63 @@ class _FakeStreamlit:
         return options[1]
 
     def image(self, img, caption=None, use_column_width=None):
-        self.calls.append(("image", img.shape, img.dtype))
+        self.calls.append(("image", img.shape, img.dtype, img.copy()))
+
+    def metric(self, label, value):
+        self.calls.append(("metric", label, value))
+
+    def empty(self):            # a placeholder is updated in place: same drawing calls
+        return self
 
     def columns(self, n):
-        outer = self
-
-        class Col:
-            def metric(self, label, value):
-                outer.calls.append(("metric", label, value))
-        return [Col() for _ in range(n)]
+        return [self for _ in range(n)]
 
     def error(self, msg):
         self.calls.append(("error", msg))
 
 
-def test_streamlit_page_wiring(pkg):
+def test_streamlit_page_streams_frames_without_a_rerun(pkg):
+    """f4: one call of build_lbm_component keeps the canvas advancing (the page's rAF loop, html:902-930) — several
+    composited images and several read-out updates per call, the tunnel survives the rerun a widget change causes."""
     from airfoil_cfd_tool_amd.streamlit_page import build_lbm_component
     st = _FakeStreamlit()
     coords = pkg.geometry.SHAPES["naca4412"]()
-    wt = build_lbm_component(coords, "NACA 4412", nx=256, ny=128, frames_per_rerun=6, st=st)
+    wt = build_lbm_component(coords, "NACA 4412", nx=256, ny=128, frames=12, frames_per_update=4, st=st)
     try:
-        assert wt is not None and wt.aoa_deg == 8.0 and wt.field == "cp" and wt.steps == 24
-        assert ("image", (128, 256, 4), np.dtype(np.uint8)) in st.calls
-        metrics = {c[1]: c[2] for c in st.calls if c[0] == "metric"}
-        assert set(metrics) == {"CL (approx)", "CD (approx)", "Reynolds", "Separation"} and metrics["Reynolds"] == "313"
-        again = build_lbm_component(coords, "NACA 4412", nx=256, ny=128, frames_per_rerun=3, st=st)
-        assert again is wt and wt.steps == 36                      # same session -> same tunnel keeps running
+        assert wt is not None and wt.aoa_deg == 8.0 and wt.field == "cp" and wt.steps == 48          # 12 frames x 4 steps
+        images = [c for c in st.calls if c[0] == "image"]
+        assert len(images) == 3 and all(c[1] == (360, 680, 4) and c[2] == np.dtype(np.uint8) for c in images)
+        assert (images[0][3] != images[-1][3]).any()                                                # the picture moved on
+        metrics = [c for c in st.calls if c[0] == "metric"]
+        assert len(metrics) == 4 * 3 and {c[1] for c in metrics} == {"CL (approx)", "CD (approx)", "Reynolds", "Separation"}
+        assert metrics[2][2] == "313"
+        again = build_lbm_component(coords, "NACA 4412", nx=256, ny=128, frames=4, frames_per_update=2, st=st)
+        assert again is wt and wt.steps == 64 and st.session_state["wt_amd_frames"] == 16          # same session -> same tunnel keeps running
+        assert len([c for c in st.calls if c[0] == "image"]) == 5
     finally:
         wt.close()
+
+
+def test_composited_png_of_a_running_tunnel(pkg, tmp_path):
+    """f2 end to end: field from the GPU colour-map kernel, tracer strokes from the GPU advection, compositor on the
+    host, PNG under the page's file name (html:980-1000)."""
+    import struct
+    from airfoil_cfd_tool_amd.compose import TrailLayer
+    from airfoil_cfd_tool_amd.tracers import Tracers
+    with pkg.WindTunnel(shape="naca2412", nx=320, ny=160, aoa_deg=6.0, name="NACA 2412 test") as wt:
+        tr, layer = Tracers(wt, n=600, seed=3), TrailLayer(1)
+        for _ in range(20):
+            wt.frame(render=False)
+            tr.draw(layer, 16.0)
+        img = wt.compose_frame(trails=layer)
+        assert img.shape == (360, 680, 4)
+        assert (layer.a > 0.3).sum() > 300                                      # strokes exist
+        # the body is drawn over field and strokes: the lattice's solid cells map to foil-coloured pixels
+        cx = 54 + int((0.3 - (-0.42)) / 1.84 * 584)
+        assert ((img[:, cx, :3] == np.array([0x0d, 0x10, 0x18])).all(axis=1)).sum() >= 4
+        path = wt.save_png(str(tmp_path / wt.png_name()), trails=layer)
+        assert path.endswith("NACA_2412_test_alpha6.0deg_lbm.png")
+        raw = open(path, "rb").read()
+        assert struct.unpack(">II", raw[16:24]) == (680, 360)
+        bare = wt.save_png(str(tmp_path / "bare.png"), composite=False)
+        assert struct.unpack(">II", open(bare, "rb").read()[16:24]) == (320, 160)
