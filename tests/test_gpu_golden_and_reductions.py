@@ -138,7 +138,7 @@ def test_render_rgba_vs_reference_render_shader(pkg, tmp_path):
             img = wt.render_rgba(name)
             assert img.shape == (32, 64, 4) and img.dtype == np.uint8 and (img[..., 3] == 255).all()
             assert np.array_equal(img[..., :3], want[mode]), name
-        path = wt.save_png(str(tmp_path / "x.png"), "speed")
+        path = wt.save_png(str(tmp_path / "x.png"), "speed", composite=False)      # the bare lattice field; composited canvas: tests/test_compose.py
         data = open(path, "rb").read()
         assert data[:8] == b"\x89PNG\r\n\x1a\n" and b"IHDR" in data[:32] and data[-8:-4] == b"IEND"
         import struct
