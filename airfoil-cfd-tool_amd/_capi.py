@@ -25,7 +25,7 @@ EXPORTS = (
     "wt_set_option", "wt_get_option",
     "wt_comm_unique_id", "wt_comm_init_rank", "wt_comm_selftest", "wt_link_local", "wt_step_group",
     "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_read_f", "wt_write_f",
-    "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_field", "wt_render_rgba", "wt_advect_tracers", "wt_sync",
+    "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_clamp_events", "wt_field", "wt_render_rgba", "wt_advect_tracers", "wt_sync",
 )
 
 
@@ -87,6 +87,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "wt_read_macro": ([H, c_void_p, c_void_p, c_void_p], c_int),
         "wt_reduce_ranges": ([H, c_double, POINTER(c_double), POINTER(c_double), POINTER(c_double)], c_int),
         "wt_forces": ([H, POINTER(c_double), POINTER(c_double), POINTER(c_int64), POINTER(c_int64)], c_int),
+        "wt_clamp_events": ([H, POINTER(c_int64), POINTER(c_int64)], c_int),
         "wt_field": ([H, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p], c_int),
         "wt_render_rgba": ([H, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p], c_int),
         "wt_advect_tracers": ([H, c_int, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_double,
@@ -235,6 +236,12 @@ class Engine:
         fx, fy, surf, rev = c_double(), c_double(), c_int64(), c_int64()
         _check(self._lib.wt_forces(self._h, byref(fx), byref(fy), byref(surf), byref(rev)))
         return fx.value, fy.value, surf.value, rev.value
+
+    def clamp_events(self):
+        """(sites at a density bound, sites at the speed bound) of the last emitted state (html:344-350)."""
+        a, b = c_int64(), c_int64()
+        _check(self._lib.wt_clamp_events(self._h, byref(a), byref(b)))
+        return a.value, b.value
 
     def field(self, mode: int, u0: float, max_s: float, cp_min: float, cp_max: float, vort_scale: float) -> np.ndarray:
         out = np.empty((self.ny, self.width), dtype=self.dtype)

@@ -226,6 +226,40 @@ __global__ __launch_bounds__(256) void k_forces(const T *__restrict__ macro, con
     }
 }
 
+// Diagnostics for the stability net (html:344-350): how many fluid sites of the owned columns sat AT a clamp in the
+// last emitted state — stored rho equal to a density bound, stored |u| at the speed bound (the stored velocity of a
+// clamped site is u * (0.35 / |u|), i.e. 0.35 up to rounding).  On demand, never in the step loop.
+struct ClampPartial { long long rho_events, u_events; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_clamp_events(const T *__restrict__ macro, const uint8_t *__restrict__ mask, Geom g,
+                                                      int i_own0, int W, ClampPartial *__restrict__ part)
+{
+    const uint8_t *m = mask + g.pitch;
+    const long mp = (long)g.nxl * g.pitch;
+    long long nr = 0, nu = 0;
+    const long total = (long)W * g.ny;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const int x = (int)(t / g.ny), j = (int)(t % g.ny);
+        const long c = (long)(i_own0 + x) * g.pitch + j;
+        if (m[c]) continue;
+        const T rho = macro[c], ux = macro[mp + c], uy = macro[2 * mp + c];
+        nr += (rho == T(0.5) || rho == T(2.0));
+        nu += ((double)ux * (double)ux + (double)uy * (double)uy >= 0.35 * 0.35 * (1.0 - 1e-6));
+    }
+    __shared__ long long sh[2][4];
+    nr = wave_sum(nr); nu = wave_sum(nu);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = nr; sh[1][w] = nu; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ClampPartial r;
+        r.rho_events = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        r.u_events = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        part[blockIdx.x] = r;
+    }
+}
+
 // RENDER_FS main() field math (html:395-420): scalar t per owned site, written in HOST layout
 // out[j*W + x]; NaN on solids.  Neighbour columns beyond the slab come from the ghost columns
 // (kept fresh by the caller), beyond the tunnel from CLAMP_TO_EDGE.

@@ -1045,6 +1045,31 @@ extern "C" int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, in
     return WT_OK;
 }
 
+extern "C" int wt_clamp_events(wt_handle *h, int64_t *rho_events, int64_t *u_events)
+{
+    WT_TRY(check_handle(h));
+    if (!rho_events || !u_events) return fail(WT_ERR_ARG, "null output");
+    if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (h->macro_stale) return fail(WT_ERR_STATE, "wt_write_f replaced the populations: (rho,ux,uy) are emitted by the next wt_step");
+    HIP_TRY(hipSetDevice(h->device));
+    const long total = (long)h->width * h->g.ny;
+    int nb = (int)((total + 255) / 256);
+    if (nb > kReduceBlocks) nb = kReduceBlocks;
+    ClampPartial *dp = reinterpret_cast<ClampPartial *>(h->partials);
+    if (h->dtype == WT_F32)
+        hipLaunchKernelGGL(k_clamp_events<float>, dim3(nb), dim3(256), 0, h->s_compute, (const float *)h->macro, h->mask, h->g, h->gl, h->width, dp);
+    else
+        hipLaunchKernelGGL(k_clamp_events<double>, dim3(nb), dim3(256), 0, h->s_compute, (const double *)h->macro, h->mask, h->g, h->gl, h->width, dp);
+    HIP_TRY(hipGetLastError());
+    ClampPartial *hp = reinterpret_cast<ClampPartial *>(h->partials_host);
+    HIP_TRY(hipMemcpyAsync(hp, dp, nb * sizeof(ClampPartial), hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    long long nr = 0, nu = 0;
+    for (int b = 0; b < nb; b++) { nr += hp[b].rho_events; nu += hp[b].u_events; }
+    *rho_events = nr; *u_events = nu;
+    return WT_OK;
+}
+
 // Vorticity (html:411-417) needs uy of the columns left and right of the slab: fetch the
 // neighbours' edge columns of the macro uy plane into this slab's innermost ghost columns.
 // TR_RCCL: collective — every rank must be inside wt_field(WT_FIELD_VORT) together.

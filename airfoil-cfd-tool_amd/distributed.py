@@ -83,6 +83,11 @@ class SlabWindTunnel(WindTunnel):
         fx, fy, surf, rev = self._all_reduce([fx, fy, float(surf), float(rev)], self._dist.ReduceOp.SUM)
         return fx, fy, int(round(surf)), int(round(rev))
 
+    def clamp_events(self):
+        a, b = self.engine.clamp_events()
+        a, b = self._all_reduce([float(a), float(b)], self._dist.ReduceOp.SUM)
+        return int(round(a)), int(round(b))
+
     # ---- plumbing ----------------------------------------------------------------------
     def _global_rank(self, group_rank: int) -> int:
         return group_rank if self.group is None else self._dist.get_global_rank(self.group, group_rank)

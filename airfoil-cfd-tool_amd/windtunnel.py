@@ -194,6 +194,10 @@ class WindTunnel:
         self.sep_frac = self.sep_frac * 0.85 + (rev / surf) * 0.15
         return cl_raw, cd_raw, rev / surf
 
+    def clamp_events(self):
+        """How many fluid sites the stability net (html:344-350) holds at a bound: (density, speed); (0, 0) when healthy."""
+        return self.engine.clamp_events()
+
     def render_field(self, max_s: Optional[float] = None, cp_min: Optional[float] = None,
                      cp_max: Optional[float] = None, field: Optional[str] = None) -> np.ndarray:
         """renderField's field math (html:530-545 + 395-420): the colour-map

@@ -166,6 +166,11 @@ int wt_reduce_ranges(wt_handle *h, double u0, double *max_s, double *cp_min, dou
  * (html:676-679, 699). */
 int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, int64_t *rev);
 
+/* Diagnostics of the stability net STEP_FS applies silently (html:344-350; SURVEY §5 "clamp-event counter"): the number
+ * of owned fluid sites whose last emitted state sits at a density bound (rho = 0.5 or 2.0) and at the speed bound
+ * (|u| = 0.35).  Both are 0 in a healthy run.  Per-slab partials, like wt_forces. */
+int wt_clamp_events(wt_handle *h, int64_t *rho_events, int64_t *u_events);
+
 /* Replaces RENDER_FS main()'s field math (html:395-420): the scalar t handed to
  * the colour map, [NY][W], NaN on solid sites.  max_s/cp_min/cp_max are the
  * uniforms of html:540-542, vort_scale html:528/543. */

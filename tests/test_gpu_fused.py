@@ -70,9 +70,19 @@ def test_fused_low_tau_clamp_and_mask_change(pkg, oracle_c):
         e.set_mask(m1); e.init_equilibrium(0.10); e.step(300, 0.5004, 0.10)
         e.set_mask(m2); e.step(100, 0.5004, 0.09)
         f, m = e.read_f(), e.read_macro()
+        events = e.clamp_events()
     fr, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float32)
     fr, mr = oracle_c.run(m2, 100, 0.5004, 0.09, np.float32, f=fr)
     assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr))
+    # the clamp-event diagnostic (html:344-350) counted on the oracle's macro state
+    fluid = m2 == 0
+    rho, ux, uy = (a.astype(np.float64) for a in mr)
+    want = (int(((mr[0] == np.float32(0.5)) | (mr[0] == np.float32(2.0)))[fluid].sum()),
+            int(((ux * ux + uy * uy) >= 0.35 * 0.35 * (1 - 1e-6))[fluid].sum()))
+    assert events == want and want[1] > 0                      # this run does hit the speed clamp
+    with pkg.Engine(nx, ny) as e:
+        e.set_mask(m2); e.init_equilibrium(0.06); e.step(50, 0.58, 0.06)
+        assert e.clamp_events() == (0, 0)                       # a healthy run never touches the net
 
 
 def test_fused_toggle_midrun_and_4096(pkg):
@@ -177,3 +187,20 @@ def test_fuse_auto_only_where_it_pays(pkg):
         small.set_option("fuse_steps", 2)
         assert small.get_option("fuse_active") == 1.0
         small.step(6, 0.58, 0.06); big.step(6, 0.58, 0.06)
+
+
+def test_set_mask_stays_interactive(pkg):
+    """The AoA slider (html:943-947, 35 ms debounce) re-uploads the mask: upload, tile classes, bounce codes and the
+    marching plan together must stay far below a frame (VERDICT r1 #10: <= 5 ms at 1024x512)."""
+    import time
+    for (nx, ny), limit_ms in (((1024, 512), 5.0), ((4096, 4096), 25.0)):
+        masks = [_body(pkg, nx, ny, "naca2412", a) for a in (4.0, 4.5, 5.0, 5.5)]
+        with pkg.Engine(nx, ny) as e:
+            e.set_option("fuse_steps", 2)
+            e.set_mask(masks[0]); e.init_equilibrium(0.06); e.step(4, 0.58, 0.06); e.sync()
+            ts = []
+            for k in range(12):
+                t0 = time.perf_counter(); e.set_mask(masks[k % 4]); ts.append((time.perf_counter() - t0) * 1e3)
+            assert e.get_option("fuse_active") == 1.0
+            assert sorted(ts)[len(ts) // 2] <= limit_ms, ts
+            e.step(6, 0.58, 0.06)
