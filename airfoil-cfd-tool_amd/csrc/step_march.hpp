@@ -38,6 +38,10 @@
 #include <vector>
 #include "step_fast.hpp"
 
+#ifndef WT_STORE_AUX
+#define WT_STORE_AUX 2      // cache policy of the lattice stores: nt (written once, read by the NEXT pass); measured 2-4.5 % faster than 0
+#endif
+
 namespace wt {
 
 static constexpr int MARCH_WIN = 256;            // window height = window pitch
@@ -95,6 +99,26 @@ __global__ __launch_bounds__(256) void k_bounce_codes(const uint8_t *__restrict_
     }
 }
 
+// seam_plain[(b - 1) * nxl + x] = 1 <=> both sites next to seam b in column x (rows 256b-1 and 256b) are plain interior
+// fluid: not solid, no solid neighbour, not on an inlet / outlet column or the top row.  The halo kernels then read one
+// coalesced byte instead of four scattered mask / code bytes per thread.
+__global__ __launch_bounds__(256) void k_seam_flags(const uint8_t *__restrict__ mask, const uint8_t *__restrict__ bcode, uint8_t *__restrict__ seam_plain,
+                                                    Geom g, int nwin)
+{
+    const long total = (long)(nwin - 1) * g.nxl;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % g.nxl);
+    const int b = 1 + (int)(t / g.nxl);
+    const int j = MARCH_WIN * b - 1;
+    const uint8_t *m = mask + g.pitch;
+    const long c = (long)x * g.pitch + j;
+    const int gi = x + g.gi0;
+    bool plain = false;
+    if (j + 1 < g.ny - 1 && gi > 0 && gi < g.nx_g - 1) plain = bcode[c] == 0 && bcode[c + 1] == 0 && m[c] == 0 && m[c + 1] == 0;
+    seam_plain[t] = plain ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // once per pass: the halo table
 // ------------------------------------------------------------------------------------------------
@@ -133,7 +157,7 @@ __device__ __forceinline__ void site_step1(const float *__restrict__ s, const ui
 // input of the two sites; anything else falls back to site_step1.  The loads are a gather (neighbouring threads are
 // one column = pitch * 4 bytes apart); that, not the arithmetic, is this kernel's cost.
 template <int FD>
-__global__ __launch_bounds__(256) void k_halo_rows(const float *__restrict__ fs, const uint8_t *__restrict__ mask, const uint8_t *__restrict__ bcode,
+__global__ __launch_bounds__(256) void k_halo_rows(const float *__restrict__ fs, const uint8_t *__restrict__ mask, const uint8_t *__restrict__ seam_plain,
                                                    float *__restrict__ halo, Geom g, int nwin, FastDiv fdv, float U0)
 {
     const long total = (long)(nwin - 1) * g.nxl;
@@ -148,11 +172,9 @@ __global__ __launch_bounds__(256) void k_halo_rows(const float *__restrict__ fs,
     const float *s = fs + g.pitch;
     const uint8_t *m = mask + g.pitch;
     const long c = (long)x * g.pitch + j;
-    const int gi = x + g.gi0;
     float lo[9], hi[9];
     const bool two = (j + 1 < g.ny);
-    const bool plain = two && gi > 0 && gi < g.nx_g - 1 && j + 1 < g.ny - 1 &&
-                       bcode[c] == 0 && bcode[c + 1] == 0 && m[c] == 0 && m[c + 1] == 0;
+    const bool plain = seam_plain[(long)(b - 1) * g.nxl + x] != 0;
     if (plain) {
         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
         float a[9], d[9], rho, ux, uy;
@@ -174,6 +196,49 @@ __global__ __launch_bounds__(256) void k_halo_rows(const float *__restrict__ fs,
     rec[1] = make_float4(hi[4], hi[7], hi[8], 0.0f);
 }
 
+// The same table from the seam buffer S that the PREVIOUS marching pass wrote beside the lattice it produced (valid
+// only then: the library tracks it).  Neighbouring threads read neighbouring 192-byte records: coalesced, 13 MB instead
+// of a 130 MB gather.  Sites near the body / on the inlet and outlet columns fall back to site_step1 on the lattice.
+template <int FD>
+__global__ __launch_bounds__(256) void k_halo_from_seams(const float *__restrict__ fs, const float *__restrict__ seams, const uint8_t *__restrict__ mask,
+                                                         const uint8_t *__restrict__ seam_plain, float *__restrict__ halo, Geom g, int nwin, FastDiv fdv, float U0)
+{
+    const long total = (long)(nwin - 1) * g.nxl;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % g.nxl);
+    const int b = 1 + (int)(t / g.nxl);
+    const int j = MARCH_WIN * b - 1;
+    if (j >= g.ny) return;
+    const float *s = fs + g.pitch;
+    const uint8_t *m = mask + g.pitch;
+    float lo[9], hi[9];
+    const bool two = (j + 1 < g.ny);
+    const bool plain = seam_plain[t] != 0;
+    if (plain) {
+        float a[9], d[9], rho, ux, uy;
+        const float *rec = seams + ((long)b * (g.nxl + 2) + x + 1) * 48;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const float *r = rec - (long)ex_of(k) * 48 + 2 * k;
+            const float2 below = *reinterpret_cast<const float2 *>(r);            // rows 256b-2, 256b-1
+            const float2 above = *reinterpret_cast<const float2 *>(r + 24);       // rows 256b, 256b+1
+            const float q[4] = {below.x, below.y, above.x, above.y};
+            a[k] = q[1 - ey_of(k)];      // input of row 256b-1
+            d[k] = q[2 - ey_of(k)];      // input of row 256b
+        }
+        collide_fd<FD>(a, fdv, lo, rho, ux, uy);
+        collide_fd<FD>(d, fdv, hi, rho, ux, uy);
+    } else {
+        site_step1<FD>(s, m, g, x, j, fdv, U0, lo);
+        if (two) site_step1<FD>(s, m, g, x, j + 1, fdv, U0, hi);
+        else { for (int k = 0; k < 9; k++) hi[k] = 0.0f; }
+    }
+    float4 *out = reinterpret_cast<float4 *>(halo + ((long)b * (g.nxl + 2) + x + 1) * 8);
+    out[0] = make_float4(lo[2], lo[5], lo[6], 0.0f);
+    out[1] = make_float4(hi[4], hi[7], hi[8], 0.0f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // units
 // ------------------------------------------------------------------------------------------------
@@ -188,6 +253,7 @@ struct MarchParams {
     const uint8_t *bcode;      // bounce codes, column 0 first
     const uint8_t *wcls;       // window-tile classes [nwin][nxl + 2]
     const float *halo;         // H[nwin + 1][nxl + 2][8], see k_halo_rows
+    float *seams;              // S[nwin + 1][nxl + 2][2][24]: the rows around every window seam of the DESTINATION lattice, see k_halo_from_seams
     const MarchUnit *units;
     int nunits;
     Geom g;
@@ -222,11 +288,27 @@ __device__ __forceinline__ V4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, uns
     o.v[0] = __uint_as_float(x.x); o.v[1] = __uint_as_float(x.y); o.v[2] = __uint_as_float(x.z); o.v[3] = __uint_as_float(x.w);
     return o;
 }
-__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const V4 &v)
+__device__ __forceinline__ u4v bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const V4 &v)
 {
     u4v x;
     x.x = __float_as_uint(v.v[0]); x.y = __float_as_uint(v.v[1]); x.z = __float_as_uint(v.v[2]); x.w = __float_as_uint(v.v[3]);
-    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, WT_STORE_AUX);
+    return x;                                                                  // for store_data_fence()
+}
+// STORE-DATA HAZARD (measured on MI355X, ROCm 7.2): a buffer_store_dwordx4 whose soffset is an SGPR reads its data
+// VGPRs a little after it issues.  A VALU instruction right behind it that overwrites one of them can win that race for
+// the last lanes of each 16-lane group when the memory pipe is backed up — the store then writes the NEW register
+// contents (seen as 4-lane groups of wrong macro values at the outlet column of a 16384 x 4096 lattice, nowhere else
+// and not on every run).  hipcc pads this hazard only for stores WITHOUT a register soffset (LLVM GCNHazardRecognizer::
+// createsVALUHazard), so the pad is ours: the asm keeps every data tuple of a store group live up to this point and
+// its `s_nop 1` gives the two wait states after the group's last store.  tools/check_store_hazard.py verifies the
+// generated ISA (run by tests/test_build_hazards.py).
+__device__ __forceinline__ void store_data_fence(const u4v (&d)[12], int n)
+{
+    if (n == 12)
+        asm volatile("s_nop 1" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]), "v"(d[9]), "v"(d[10]), "v"(d[11]));
+    else
+        asm volatile("s_nop 1" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]));
 }
 __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b)
 {
@@ -239,6 +321,10 @@ struct MarchAddr {
     __amdgpu_buffer_rsrc_t rs, rd, rm;   // source lattice, destination lattice, macro planes
     unsigned voff;                       // j0 * 4
     unsigned voff_st;                    // the same for stores; lanes beyond the last row: out of range (dropped by the buffer check)
+    __amdgpu_buffer_rsrc_t rseam;        // seam buffer S
+    unsigned voff_lo, voff_hi;           // lanes 0..11: byte offsets of their slot in the two half records this window writes; other lanes: out of range
+    float *lds_w, *lds_r;                // this lane's LDS address for staging (write) and for the transposed read-back
+    int lane;
     unsigned P4, pitch4, mp4;            // plane / column / macro-plane strides in bytes
 };
 
@@ -398,13 +484,43 @@ __device__ __forceinline__ void march_outlet_macro(const V4 (&q9)[9], V4 (&mac)[
 template <bool EMIT>
 __device__ __forceinline__ void march_store(const MarchAddr &a, int col, const V4 (&out)[9], const V4 (&mac)[3])
 {
+    u4v d[12];
 #pragma unroll
-    for (int k = 0; k < 9; k++) bstore(a.rd, a.voff_st, lat_off(a, k, col, 0), out[k]);
+    for (int k = 0; k < 9; k++) d[k] = bstore(a.rd, a.voff_st, lat_off(a, k, col, 0), out[k]);
     if (EMIT) {
         const unsigned mo = (unsigned)col * a.pitch4;
 #pragma unroll
-        for (int q = 0; q < 3; q++) bstore(a.rm, a.voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
+        for (int q = 0; q < 3; q++) d[9 + q] = bstore(a.rm, a.voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
     }
+    store_data_fence(d, EMIT ? 12 : 9);
+    // The two rows on either side of the window seams go, once more, into the seam buffer S (lane 0 holds rows 0,1 — above
+    // seam w; lane 63 rows 254,255 — below seam w+1).  They pass through LDS so that 12 lanes write each half record as 96
+    // contiguous, 32-byte-aligned bytes (whole memory sectors: two-lane 8-byte stores straight from lanes 0 / 63 cost more
+    // than the table saves — partial sectors are read-modify-written).  Software-pipelined: this call only STAGES the
+    // values (one ds_write_b64 per direction, every lane, no branch: lanes 1..62 hit a scratch slot); seam_fetch() at the
+    // top of the next iteration reads them back transposed and seam_flush() stores them beside that iteration's stores,
+    // so no LDS latency is exposed.  The next pass builds its halo table from S with coalesced loads
+    // (k_halo_from_seams) instead of a 130 MB gather (k_halo_rows).
+    const bool top = a.lane == 63;
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        *reinterpret_cast<float2 *>(a.lds_w + 2 * k) = make_float2(top ? out[k].v[2] : out[k].v[0], top ? out[k].v[3] : out[k].v[1]);
+}
+
+// seam values staged by the previous march_store, transposed: lane k < 9 gets direction k's pair of rows
+struct SeamPair { float2 below, above; };
+__device__ __forceinline__ SeamPair seam_fetch(const MarchAddr &a)
+{
+    SeamPair r;
+    r.below = *reinterpret_cast<const float2 *>(a.lds_r);         // rows 254,255 (staged by lane 63)
+    r.above = *reinterpret_cast<const float2 *>(a.lds_r + 24);    // rows 0,1     (staged by lane 0)
+    return r;
+}
+__device__ __forceinline__ void seam_flush(const MarchAddr &a, int col, const SeamPair &r)
+{
+    const unsigned so = (unsigned)(col + 1) * 192u;
+    bstore2(a.rseam, a.voff_hi, so, r.below.x, r.below.y);        // -> seam w+1, half 0
+    bstore2(a.rseam, a.voff_lo, so, r.above.x, r.above.y);        // -> seam w,   half 1
 }
 
 // Step 1 of column x -> G (all nine directions).  `in` holds the streamed inputs of column x (modified in place).
@@ -448,51 +564,14 @@ __device__ __forceinline__ void march_step1(const MarchParams &p, const MarchAdd
     if (far_win) march_far_rows<false>(j0, p.g.ny, p.U0, feq0, G, mac);
 }
 
-template <bool BODY, bool EMIT, int FD, int MINW, int PF = 1>
-__global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
+// One unit: marched columns [ia, ib) of window w.  BODY = false: the unit's footprint is plain interior fluid — no
+// class tests, no mask, no inlet / outlet logic, fewer live registers (no spills); BODY = true: everything.
+template <bool BODY, bool EMIT, int FD>
+__device__ __forceinline__ void march_unit(const MarchParams &p, MarchAddr &a, __amdgpu_buffer_rsrc_t rh, unsigned hoff, int ia, int ib, int uflags,
+                                           int j0, int lane, bool far_win, unsigned long long nonfast_m, unsigned long long solid_m,
+                                           const float (&feq0)[9])
 {
     const Geom &g = p.g;
-    const int lane = threadIdx.x & 63;
-    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= p.nunits) return;
-    if (p.rev & 1) u = p.nunits - 1 - u;
-    const MarchUnit un = p.units[u];
-    const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
-    const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
-    const int row0 = w * MARCH_WIN;
-    const int j0 = row0 + lane * 4;
-    const bool far_win = (w == 0) || (row0 + MARCH_WIN >= g.ny);   // the window holds row 0 or row NY-1
-    MarchAddr a;
-    a.rs = march_rsrc(p.fs, p.lat_bytes);
-    a.rd = march_rsrc(p.fd, p.lat_bytes);
-    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
-    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * 4u;          // lanes beyond the last row re-read the window's first rows (cached) and store nothing
-    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * 4u : p.lat_bytes;   // >= num_records of both the lattice and the macro buffer
-    a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
-    // halo table: lanes 0..5 fetch, for step 2 of column c, {G2(c), G5(c-1), G6(c+1)} of the row below the window
-    // (seam w) and {G4(c), G7(c+1), G8(c-1)} of the row above it (seam w+1); record = 8 floats per (seam, column)
-    const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.halo, (unsigned)((unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 32u));
-    unsigned hoff;
-    {
-        const int hl = lane < 6 ? lane : 0;
-        const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
-        const int slot = hl < 3 ? hl : hl + 1;
-        const int seam = hl < 3 ? w : w + 1;
-        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 32 + slot * 4);
-    }
-    float feq0[9];
-    feq_all<float>(1.0f, p.U0, 0.0f, feq0);                       // far-field populations (html:314-322)
-
-    // BODY: classes of columns ia-1 .. ib (lane l <-> column ia-1+l): two 64-bit scalars
-    unsigned long long nonfast_m = 0, solid_m = 0;
-    if (BODY) {
-        const int n = ib - ia + 2;
-        uint8_t cls = WC_FAST;
-        if (lane < n) cls = p.wcls[(long)w * (g.nxl + 2) + ia + lane];
-        nonfast_m = __ballot(cls != WC_FAST);
-        solid_m = __ballot(cls == WC_SOLID);
-        if (p.rev & 8) { nonfast_m = 0; solid_m = 0; }       // (tools/kmarch: timing experiment, wrong results)
-    }
 #define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 1)) & 1ULL) != 0)
 #define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 1)) & 1ULL) != 0)
 #define STEP1(x, in, G) march_step1<BODY, FD>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
@@ -511,15 +590,13 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
     STEP1(ia, in, Gc);
     march_load_stream(a, ia + 1, in);
     unsigned hv = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (unsigned)ia * 32u, 0);
-    V4 nxt[9];
-    if (PF == 2) march_load_stream(a, (ia + 2 <= ib) ? ia + 2 : ia + 1, nxt);
+    int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
 #pragma unroll 1
     for (int c = ia; c < ib; c++) {
-        V4 nxt2[9];
-        if (PF == 2) march_load_stream(a, (c + 3 <= ib) ? c + 3 : ib, nxt2);  // two columns ahead
-        else if (!(p.rev & 2)) march_load_stream(a, (c + 2 <= ib) ? c + 2 : c + 1, nxt);   // prefetch (last one: harmless re-load)
-        else { for (int k = 0; k < 9; k++) nxt[k] = in[k]; }                   // (tools/kmarch: arithmetic only)
+        V4 nxt[9];
+        march_load_stream(a, (c + 2 <= ib) ? c + 2 : c + 1, nxt);             // prefetch (last one: harmless re-load)
         const unsigned hv_next = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (unsigned)(c + 1) * 32u, 0);
+        const SeamPair sp = seam_fetch(a);                                    // staged by the previous iteration's march_store
         STEP1(c + 1, in, G);                                                  // step 1 of column c+1
         const float hb2 = __uint_as_float(__builtin_amdgcn_readlane(hv, 0)), hb5 = __uint_as_float(__builtin_amdgcn_readlane(hv, 1)),
                     hb6 = __uint_as_float(__builtin_amdgcn_readlane(hv, 2)), ha4 = __uint_as_float(__builtin_amdgcn_readlane(hv, 3)),
@@ -561,7 +638,9 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
             march_collide<FD, EMIT>(fin, p.fdv, out, mac);
             if (far_win) march_far_rows<EMIT>(j0, g.ny, p.U0, feq0, out, mac);
         }
-        if (!(p.rev & 4) || c + 1 == ib) march_store<EMIT>(a, c, out, mac);
+        march_store<EMIT>(a, c, out, mac);
+        seam_flush(a, seam_col, sp);
+        seam_col = c;
         if (BODY && __builtin_expect((uflags & MU_OUTLET_AFTER) && c + 1 == ib, 0)) {
             // outlet column NX-1 (html:301-312): its step-2 value is the step-1 state of column NX-2 (= Gc), its own
             // step-1 state (solid sites only) is G
@@ -572,16 +651,87 @@ __global__ __launch_bounds__(256, MINW) void k_march(MarchParams p)
             for (int k = 0; k < 9; k++) out[k] = Gc[k];
             if (EMIT) march_outlet_macro(Gc, mac);
             if (__ballot(solid4 != 0) != 0ULL) march_solid<EMIT>(out, mac, solid4, ownp);
+            seam_flush(a, seam_col, seam_fetch(a));          // column c's seam rows, before the staging area is reused
             march_store<EMIT>(a, c + 1, out, mac);
+            seam_col = c + 1;
         }
         G158m[0] = Gc[1]; G158m[1] = Gc[5]; G158m[2] = Gc[8];
 #pragma unroll
-        for (int k = 0; k < 9; k++) { Gc[k] = G[k]; in[k] = nxt[k]; if (PF == 2) nxt[k] = nxt2[k]; }
+        for (int k = 0; k < 9; k++) { Gc[k] = G[k]; in[k] = nxt[k]; }
         hv = hv_next;
     }
+    seam_flush(a, seam_col, seam_fetch(a));
 #undef NONFAST
 #undef ALLSOLID
 #undef STEP1
+}
+
+template <bool EMIT, int FD>
+__global__ __launch_bounds__(256, 2) void k_march(MarchParams p)
+{
+    const Geom &g = p.g;
+    const int lane = threadIdx.x & 63;
+    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= p.nunits) return;
+    if (p.rev & 1) u = p.nunits - 1 - u;
+    const MarchUnit un = p.units[u];
+    const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
+    const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
+    if (ib <= ia) return;                                          // padding unit (keeps the block -> XCD pattern of the list)
+    const int row0 = w * MARCH_WIN;
+    const int j0 = row0 + lane * 4;
+    const bool far_win = (w == 0) || (row0 + MARCH_WIN >= g.ny);   // the window holds row 0 or row NY-1
+    MarchAddr a;
+    a.rs = march_rsrc(p.fs, p.lat_bytes);
+    a.rd = march_rsrc(p.fd, p.lat_bytes);
+    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
+    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * 4u;          // lanes beyond the last row re-read the window's first rows (cached) and store nothing
+    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * 4u : p.lat_bytes;   // >= num_records of both the lattice and the macro buffer
+    a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
+    // halo table: lanes 0..5 fetch, for step 2 of column c, {G2(c), G5(c-1), G6(c+1)} of the row below the window
+    // (seam w) and {G4(c), G7(c+1), G8(c-1)} of the row above it (seam w+1); record = 8 floats per (seam, column)
+    const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.halo, (unsigned)((unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 32u));
+    unsigned hoff;
+    {
+        const int hl = lane < 6 ? lane : 0;
+        const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
+        const int slot = hl < 3 ? hl : hl + 1;
+        const int seam = hl < 3 ? w : w + 1;
+        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 32 + slot * 4);
+    }
+    {
+        // S record of (seam b, column x) = 192 bytes: half 0 = rows 256b-2, 256b-1 (written by window b-1), half 1 = rows
+        // 256b, 256b+1 (written by window b); a half = 12 slots of 2 floats, slot k < 9 = direction k
+        // per wave: below[24] (lane 63 stages pairs 0..8, slots 9..11 stay zero), above[24] (lane 0), then a scratch area
+        // the other 62 lanes stage into (an LDS write per lane is cheaper than a branch around two-lane writes)
+        __shared__ float seam_lds[4][48 + 160];
+        float *wl = &seam_lds[threadIdx.x >> 6][0];
+        a.lane = lane;
+        a.lds_w = lane == 63 ? wl : (lane == 0 ? wl + 24 : wl + 48 + 2 * lane);
+        a.lds_r = wl + 2 * (lane < 12 ? lane : 0);
+        if (lane < 48) wl[lane] = 0.0f;
+        const unsigned sbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 192u;
+        a.rseam = march_rsrc(p.seams, sbytes);
+        const unsigned rec = (unsigned)(g.nxl + 2) * 192u;
+        a.voff_lo = lane < 12 ? (unsigned)w * rec + 96u + (unsigned)lane * 8u : sbytes;
+        a.voff_hi = lane < 12 ? (unsigned)(w + 1) * rec + (unsigned)lane * 8u : sbytes;
+    }
+    float feq0[9];
+    feq_all<float>(1.0f, p.U0, 0.0f, feq0);                       // far-field populations (html:314-322)
+
+    // classes of columns ia-1 .. ib (lane l <-> column ia-1+l): two 64-bit scalars
+    unsigned long long nonfast_m, solid_m;
+    {
+        const int n = ib - ia + 2;
+        uint8_t cls = WC_FAST;
+        if (lane < n) cls = p.wcls[(long)w * (g.nxl + 2) + ia + lane];
+        nonfast_m = __ballot(cls != WC_FAST);
+        solid_m = __ballot(cls == WC_SOLID);
+    }
+    // a unit whose whole footprint (columns ia-1 .. ib) is plain interior fluid takes the lean loop
+    const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= 2 && ib + g.gi0 <= g.nx_g - 2 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
+    if (lean) march_unit<false, EMIT, FD>(p, a, rh, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+    else march_unit<true, EMIT, FD>(p, a, rh, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
 }
 
 // ------------------------------------------------------------------------------------------------

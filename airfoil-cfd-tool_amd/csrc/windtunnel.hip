@@ -100,6 +100,9 @@ struct wt_handle {
     uint8_t *bcode = nullptr;            // bounce codes, (nxl+2) * pitch
     uint8_t *wcls = nullptr;             // window-tile classes, nwin * (nxl+2)
     float *halo_tab = nullptr;           // halo table of the marching kernels, (nwin+1) * (nxl+2) * 8
+    float *seams = nullptr;              // seam rows written by a marching pass beside its output lattice, (nwin+1) * (nxl+2) * 48
+    uint8_t *seam_plain = nullptr;       // per (seam, column): both sites next to the seam are plain interior fluid, (nwin-1) * nxl
+    bool seams_valid = false;            // `seams` describes lattice f[cur] (set by a marching pass, cleared by everything else that writes f)
     MarchUnit *d_units = nullptr;
     size_t units_cap = 0;
     int n_units = 0, n_win = 0, nonfast_tiles = 0;
@@ -260,6 +263,8 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->bcode) (void)hipFree(h->bcode);
     if (h->wcls) (void)hipFree(h->wcls);
     if (h->halo_tab) (void)hipFree(h->halo_tab);
+    if (h->seams) (void)hipFree(h->seams);
+    if (h->seam_plain) (void)hipFree(h->seam_plain);
     if (h->d_units) (void)hipFree(h->d_units);
     if (h->d_nbad) (void)hipFree(h->d_nbad);
     if (h->partials) (void)hipFree(h->partials);
@@ -327,6 +332,17 @@ static int rebuild_fuse_plan(wt_handle *h)
         HIP_TRY(hipMemsetAsync(h->halo_tab, 0, hbytes, h->s_compute));
         h->device_bytes += (long long)hbytes;
     }
+    if (!h->seams) {
+        const size_t sbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 48 * sizeof(float);
+        HIP_TRY(hipMalloc((void **)&h->seams, sbytes));
+        HIP_TRY(hipMemsetAsync(h->seams, 0, sbytes, h->s_compute));
+        h->device_bytes += (long long)sbytes;
+        h->seams_valid = false;
+    }
+    if (!h->seam_plain && nwin > 1) {
+        HIP_TRY(hipMalloc((void **)&h->seam_plain, (size_t)(nwin - 1) * g.nxl));
+        h->device_bytes += (long long)(nwin - 1) * g.nxl;
+    }
     if (!h->bcode) {
         HIP_TRY(hipMalloc((void **)&h->bcode, cbytes));
         HIP_TRY(hipMemsetAsync(h->bcode, 0, cbytes, h->s_compute));
@@ -337,6 +353,11 @@ static int rebuild_fuse_plan(wt_handle *h)
     const long nt = (long)(g.nxl + 2) * nwin;
     hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->wcls, g, nwin);
     hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->bcode, g);
+    if (nwin > 1) {
+        const long nth = (long)(nwin - 1) * g.nxl;
+        hipLaunchKernelGGL(k_seam_flags, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
+                           h->seam_plain, g, nwin);
+    }
     HIP_TRY(hipGetLastError());
     h->host_wcls.resize(wbytes);
     HIP_TRY(hipMemcpyAsync(h->host_wcls.data(), h->wcls, wbytes, hipMemcpyDeviceToHost, h->s_compute));
@@ -488,6 +509,7 @@ extern "C" int wt_init_equilibrium(wt_handle *h, double u0)
     h->cur = 0;
     h->inited = true;
     h->macro_stale = false;
+    h->seams_valid = false;
     h->steps_done = 0;
     h->ghost_valid = h->halo;     // a uniform state is exact everywhere, ghosts included
     return WT_OK;
@@ -578,6 +600,7 @@ static int check_steppable(wt_handle *h, int nsteps, double tau, double u0)
 // Enqueue the refresh of this slab's ghost columns (lattice `cur`) on its comm stream.
 static int halo_begin(wt_handle *h)
 {
+    h->seams_valid = false;              // the refreshed ghost columns are not in the seam buffer
     HIP_TRY(hipEventRecord(h->ev_state, h->s_compute));
     HIP_TRY(hipStreamWaitEvent(h->s_comm, h->ev_state, 0));
     if (h->transport == TR_RCCL) WT_TRY(exchange_rccl(h)); else WT_TRY(exchange_local(h));
@@ -610,6 +633,7 @@ static int step_compute(wt_handle *h, double tau, double u0, bool emit, bool ref
     }
     h->cur = 1 - h->cur;
     h->steps_done += 1;
+    h->seams_valid = false;
     return WT_OK;
 }
 
@@ -648,7 +672,7 @@ template <bool EMIT, int FD>
 static void launch_march(const MarchParams &p, hipStream_t st)
 {
     if (p.nunits <= 0) return;
-    hipLaunchKernelGGL((k_march<true, EMIT, FD, 2>), dim3((unsigned)((p.nunits + 3) / 4)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((k_march<EMIT, FD>), dim3((unsigned)((p.nunits + 3) / 4)), dim3(256), 0, st, p);
 }
 
 static void launch_march_any(const MarchParams &p, bool emit, bool fd, hipStream_t st)
@@ -667,7 +691,7 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     p.fs = fptr<float>(h, h->cur);
     p.fd = fptr<float>(h, 1 - h->cur);
     p.macro = reinterpret_cast<float *>(h->macro);
-    p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls; p.halo = h->halo_tab;
+    p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls; p.halo = h->halo_tab; p.seams = h->seams;
     p.g = g;
     p.lat_bytes = (unsigned)((size_t)9 * g.plane * 4);
     p.nwin_total = h->n_win;
@@ -677,14 +701,22 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // the step-1 populations that cross the window seams
         const long nth = (long)(h->n_win - 1) * g.nxl;
-        if (fd) hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, (const uint8_t *)h->bcode, h->halo_tab, g, h->n_win, p.fdv, p.U0);
-        else hipLaunchKernelGGL((k_halo_rows<0>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, p.fs, (const uint8_t *)h->mask, (const uint8_t *)h->bcode, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+        const dim3 grid((unsigned)((nth + 255) / 256)), block(256);
+        const uint8_t *mk = h->mask, *bc = h->seam_plain;
+        if (h->seams_valid) {   // the previous pass left the seam rows of this lattice in `seams`: coalesced loads
+            if (fd) hipLaunchKernelGGL((k_halo_from_seams<1>), grid, block, 0, st, p.fs, (const float *)h->seams, mk, bc, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+            else hipLaunchKernelGGL((k_halo_from_seams<0>), grid, block, 0, st, p.fs, (const float *)h->seams, mk, bc, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+        } else {                // gather from the lattice (first pass after a single step, an upload, a ghost refresh)
+            if (fd) hipLaunchKernelGGL((k_halo_rows<1>), grid, block, 0, st, p.fs, mk, bc, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+            else hipLaunchKernelGGL((k_halo_rows<0>), grid, block, 0, st, p.fs, mk, bc, h->halo_tab, g, h->n_win, p.fdv, p.U0);
+        }
     }
     p.units = h->d_units; p.nunits = h->n_units;
     launch_march_any(p, emit, fd, st);
     HIP_TRY(hipGetLastError());
     h->cur = 1 - h->cur;
     h->steps_done += 2;
+    h->seams_valid = true;                       // the pass wrote the seam rows of the lattice it produced
     if (h->nranks > 1) h->ghost_valid -= 2;      // two columns of ghost validity consumed
     return WT_OK;
 }
@@ -956,6 +988,7 @@ extern "C" int wt_write_f(wt_handle *h, const void *f_in)
     }
     WT_TRY(h->dtype == WT_F32 ? write_f_impl<float>(h, f_in) : write_f_impl<double>(h, f_in));
     h->inited = true;
+    h->seams_valid = false;
     h->macro_stale = true;   // the macro planes still hold the previous state's (rho,ux,uy)
     h->ghost_valid = 0;      // ghosts must be refreshed from the neighbours before the next step
     h->steps_done = 0;

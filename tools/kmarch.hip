@@ -20,7 +20,7 @@ using namespace wt;
 
 struct Lattice {
     int nx, ny; Geom g; int tpc, nwin; size_t lat;
-    float *f0, *f1, *f2, *f3, *macro, *macro2, *halo; uint8_t *mask, *tiles, *bcode, *wcls;
+    float *f0, *f1, *f2, *f3, *macro, *macro2, *halo, *seams; uint8_t *mask, *tiles, *bcode, *wcls, *seam_plain;
     std::vector<uint8_t> hmask;    // device layout (nx+2) x pitch
     std::vector<uint8_t> hwcls;
 };
@@ -79,9 +79,32 @@ __global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
 }
 
 struct DevPlan { MarchUnit *plain = nullptr, *body = nullptr; int nplain = 0, nbody = 0; };
-static DevPlan upload_plan(const Lattice &L, long target_units, int max_cost = 0, double alpha = 1.0)
+// order 0: chunk-major (library); 1: XCD-aware — blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), so
+// the 4-unit blocks are arranged such that all windows of one chunk land on ONE XCD (shared L2 for the lines that
+// straddle window seams); 2: window-major
+static DevPlan upload_plan(const Lattice &L, long target_units, int max_cost = 0, double alpha = 1.0, int order = 0)
 {
-    const MarchPlan pl = build_march_plan(L.hwcls.data(), L.g, target_units, max_cost, alpha);
+    MarchPlan pl = build_march_plan(L.hwcls.data(), L.g, target_units, max_cost, alpha);
+    if (order == 1) {
+        // group units by chunk start (ia): sequence of chunks; within a chunk, windows ascending
+        std::vector<std::vector<MarchUnit>> chunks;
+        for (const MarchUnit &u : pl.units) { if (chunks.empty() || chunks.back().front().ia != u.ia) chunks.emplace_back(); chunks.back().push_back(u); }
+        std::vector<MarchUnit> out;
+        for (size_t base = 0; base < chunks.size(); base += 8) {
+            const size_t nq = std::min<size_t>(8, chunks.size() - base);
+            size_t maxw = 0;
+            for (size_t q = 0; q < nq; q++) maxw = std::max(maxw, chunks[base + q].size());
+            for (size_t g = 0; g * 4 < maxw; g++)
+                for (size_t q = 0; q < 8; q++)              // block (g, q) -> XCD q
+                    for (size_t k = 0; k < 4; k++) {
+                        if (q < nq && g * 4 + k < chunks[base + q].size()) out.push_back(chunks[base + q][g * 4 + k]);
+                        else out.push_back(MarchUnit{0, 0, 0, 0});          // empty unit keeps the block -> XCD pattern
+                    }
+        }
+        pl.units = out;
+    } else if (order == 2) {
+        std::stable_sort(pl.units.begin(), pl.units.end(), [](const MarchUnit &x, const MarchUnit &y) { return x.w != y.w ? x.w < y.w : x.ia < y.ia; });
+    }
     DevPlan d; d.nbody = (int)pl.units.size();
     if (d.nbody) { CK(hipMalloc(&d.body, sizeof(MarchUnit) * d.nbody)); CK(hipMemcpy(d.body, pl.units.data(), sizeof(MarchUnit) * d.nbody, hipMemcpyHostToDevice)); }
     return d;
@@ -99,6 +122,7 @@ static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
     CK(hipMalloc(&L.macro, (size_t)3 * nx * g.pitch * 4)); CK(hipMalloc(&L.macro2, (size_t)3 * nx * g.pitch * 4));
     CK(hipMalloc(&L.mask, (size_t)(nx + 2) * g.pitch)); CK(hipMalloc(&L.tiles, (size_t)nx * L.tpc));
     CK(hipMalloc(&L.bcode, (size_t)(nx + 2) * g.pitch)); CK(hipMalloc(&L.wcls, (size_t)(nx + 2) * L.nwin));
+    CK(hipMalloc(&L.seams, (size_t)(L.nwin + 1) * (nx + 2) * 192)); CK(hipMemset(L.seams, 0, (size_t)(L.nwin + 1) * (nx + 2) * 192));
     CK(hipMalloc(&L.halo, (size_t)(L.nwin + 1) * (nx + 2) * 32)); CK(hipMemset(L.halo, 0, (size_t)(L.nwin + 1) * (nx + 2) * 32));
     L.hmask.assign((size_t)(nx + 2) * g.pitch, 0);
     auto set = [&](int x, int j) { if (x >= 0 && x < nx && j >= 0 && j < ny) L.hmask[(size_t)(x + 1) * g.pitch + j] = 1; };
@@ -125,6 +149,8 @@ static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
     hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, L.mask, L.wcls, g, L.nwin);
     CK(hipMemsetAsync(L.bcode, 0, (size_t)(nx + 2) * g.pitch, st));
     hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, st, L.mask, L.bcode, g);
+    CK(hipMalloc(&L.seam_plain, (size_t)std::max(1, L.nwin - 1) * nx));
+    if (L.nwin > 1) { const long nth = (long)(L.nwin - 1) * nx; hipLaunchKernelGGL(k_seam_flags, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const uint8_t *)L.mask, (const uint8_t *)L.bcode, L.seam_plain, g, L.nwin); }
     CK(hipStreamSynchronize(st)); CK(hipGetLastError());
     L.hwcls.resize((size_t)(nx + 2) * L.nwin);
     CK(hipMemcpy(L.hwcls.data(), L.wcls, L.hwcls.size(), hipMemcpyDeviceToHost));
@@ -143,31 +169,32 @@ static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
 }
 static void free_lattice(Lattice &L)
 {
-    (void)hipFree(L.f0); (void)hipFree(L.f1); (void)hipFree(L.f2); (void)hipFree(L.f3); (void)hipFree(L.macro); (void)hipFree(L.macro2); (void)hipFree(L.mask); (void)hipFree(L.tiles); (void)hipFree(L.bcode); (void)hipFree(L.wcls); (void)hipFree(L.halo);
+    (void)hipFree(L.f0); (void)hipFree(L.f1); (void)hipFree(L.f2); (void)hipFree(L.f3); (void)hipFree(L.macro); (void)hipFree(L.macro2); (void)hipFree(L.mask); (void)hipFree(L.tiles); (void)hipFree(L.bcode); (void)hipFree(L.wcls); (void)hipFree(L.halo); (void)hipFree(L.seams); (void)hipFree(L.seam_plain);
 }
 
 static MarchParams march_params(const Lattice &L, const float *a, float *b, float *macro, const MarchUnit *units, int nunits, float tau, float rtau, float U0, int rev)
 {
     MarchParams p;
-    p.fs = a; p.fd = b; p.macro = macro; p.mask = L.mask; p.bcode = L.bcode; p.wcls = L.wcls; p.halo = L.halo; p.g = L.g; p.nwin_total = L.nwin;
+    p.fs = a; p.fd = b; p.macro = macro; p.mask = L.mask; p.bcode = L.bcode; p.wcls = L.wcls; p.halo = L.halo; p.seams = L.seams; p.g = L.g; p.nwin_total = L.nwin;
     p.units = units; p.nunits = nunits; p.lat_bytes = (unsigned)L.lat;
     p.fdv.tau = tau; p.fdv.rtau = rtau; p.U0 = U0; p.rev = rev;
     return p;
 }
-static int g_lds_bytes = 0;   // dynamic LDS per block: limits resident blocks per CU (occupancy experiments)
+static int g_lds_bytes = 0;
+static int g_seams_valid = 0;  // 1: the halo table is computed from the seam buffer the previous pass wrote   // dynamic LDS per block: limits resident blocks per CU (occupancy experiments)
 // one pass = the plain units on `st`, the body units on `sb` (sb == st: one after the other)
-template <bool EMIT, int FD, int WP, int WB, int PF = 1>
+template <bool EMIT, int FD, int WP = 2, int WB = 2, int PF = 1>
 static void march_pass(const Lattice &L, const DevPlan &d, const float *a, float *b, float *macro, float tau, float U0, int rev, hipStream_t st, hipStream_t sb, hipEvent_t ev0, hipEvent_t ev1)
 {
     const float rtau = 1.0f / tau;
     if (L.nwin > 1) {
         const long nth = (long)(L.nwin - 1) * L.g.nxl;
         const FastDiv fdv{tau, rtau};
-        hipLaunchKernelGGL((k_halo_rows<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.bcode, L.halo, L.g, L.nwin, fdv, U0);
+        if (g_seams_valid) hipLaunchKernelGGL((k_halo_from_seams<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, fdv, U0);
+        else hipLaunchKernelGGL((k_halo_rows<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, fdv, U0);
     }
     if (sb != st) { CK(hipEventRecord(ev0, st)); CK(hipStreamWaitEvent(sb, ev0, 0)); }
-    if (d.nbody) hipLaunchKernelGGL((k_march<true, EMIT, FD, WB, PF>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), g_lds_bytes, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
-    if (d.nplain) hipLaunchKernelGGL((k_march<false, EMIT, FD, WP, PF>), dim3((unsigned)((d.nplain + 3) / 4)), dim3(256), g_lds_bytes, st, march_params(L, a, b, macro, d.plain, d.nplain, tau, rtau, U0, rev));
+    if (d.nbody) hipLaunchKernelGGL((k_march<EMIT, FD>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), g_lds_bytes, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
     if (sb != st) { CK(hipEventRecord(ev1, sb)); CK(hipStreamWaitEvent(st, ev1, 0)); }
 }
 
@@ -254,6 +281,18 @@ int main(int argc, char **argv)
         CK(hipMemset(L.f3, 0xff, L.lat));
         march_pass<false, 1, 2, 2>(L, du, L.f0, L.f3, L.macro2, tau, U0, 1, st, st, ev0, ev1);
         CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+        {   // a second pass whose halo table comes from the seam buffer of the first: 4 steps against 4 production steps
+            float *f4; CK(hipMalloc(&f4, L.lat)); CK(hipMemset(f4, 0xff, L.lat));
+            g_seams_valid = 1;
+            march_pass<false, 1, 2, 2>(L, du, L.f3, f4, L.macro2, tau, U0, 0, st, st, ev0, ev1);
+            g_seams_valid = 0;
+            step_columns<float, 3>(L.f2, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st);
+            float *f5; CK(hipMalloc(&f5, L.lat));
+            step_columns<float, 3>(L.f1, f5, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st);
+            CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+            printf("check %dx%d body, second pass from the seam buffer: %ld f values differ\n", nx, ny, compare(L, f5, f4, 9, L.g.plane, "f"));
+            CK(hipFree(f4)); CK(hipFree(f5));
+        }
         printf("check %dx%d body, 4096 units fastdiv: %d units; %ld f values differ\n", nx, ny, du.nbody, compare(L, L.f2, L.f3, 9, L.g.plane, "f"));
         free_plan(du);
     }
@@ -262,27 +301,22 @@ int main(int argc, char **argv)
     std::vector<Var> vs;
     std::vector<DevPlan> plans; plans.reserve(256);
     vs.push_back({"k_step x2 (production)", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(L.f1, b, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
-    vs.push_back({"k_halo_rows only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.bcode, L.halo, L.g, L.nwin, fdv, U0); }, {}, 1});
-    for (long U : {2048L, 4096L}) {
-        plans.push_back(upload_plan(L0, U)); DevPlan *d0 = &plans.back();
-        vs.push_back({"nobody, target " + std::to_string(U) + " units (" + std::to_string(d0->nbody) + ")", [&, d0](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L0, *d0, a, b, L0.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
-        for (double alpha : {0.5, 1.0, 2.0}) {
-            plans.push_back(upload_plan(L, U, 0, alpha)); DevPlan *d1 = &plans.back();
-            char buf[96]; snprintf(buf, sizeof buf, "body a=%.1f, target %ld units (%d)", alpha, U, d1->nbody);
-            vs.push_back({buf, [&, d1](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
-        }
-    }
-    for (int mc : {12, 16, 24}) {
-        plans.push_back(upload_plan(L, 0, mc, 1.0)); DevPlan *d1 = &plans.back();
-        vs.push_back({"body a=1, max cost " + std::to_string(mc) + " (" + std::to_string(d1->nbody) + ")", [&, d1](const float *a, float *b, int r) { march_pass<false, 1, 2, 2>(L, *d1, a, b, L.macro2, tau, U0, r, st, st, ev0, ev1); }, {}, 2});
+    vs.push_back({"k_halo_rows only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, fdv, U0); }, {}, 1});
+    vs.push_back({"k_halo_from_seams only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_from_seams<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, fdv, U0); }, {}, 1});
+    for (int force_body : {0, 2}) for (int sv : {0, 1}) {
+        plans.push_back(upload_plan(L0, 4096)); DevPlan *d0 = &plans.back();
+        const std::string tag = std::string(sv ? "[seam buffer] " : "[gather] ") + (force_body ? "[body loop only] " : "");
+        vs.push_back({tag + "nobody 4096 units", [&, d0, sv, force_body](const float *a, float *b, int r) { g_seams_valid = sv; march_pass<false, 1>(L0, *d0, a, b, L0.macro2, tau, U0, r | force_body, st, st, ev0, ev1); g_seams_valid = 0; }, {}, 2});
+        plans.push_back(upload_plan(L, 4096, 0, 2.0)); DevPlan *d1 = &plans.back();
+        vs.push_back({tag + "body a=2 4096 units", [&, d1, sv, force_body](const float *a, float *b, int r) { g_seams_valid = sv; march_pass<false, 1>(L, *d1, a, b, L.macro2, tau, U0, r | force_body, st, st, ev0, ev1); g_seams_valid = 0; }, {}, 2});
     }
     if (argc > 4 && std::string(argv[4]) == "prof") {
         // one variant per kernel name, few launches: for rocprofv3 --pmc
         DevPlan dp = upload_plan(L0, 4096);
         for (int q = 0; q < 6; q++) {
             const float *a = (q & 1) ? L0.f3 : L0.f0; float *b = (q & 1) ? L0.f0 : L0.f3;
-            march_pass<false, 0, 2, 2>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
-            march_pass<false, 1, 2, 2>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
+            march_pass<false, 0>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
+            march_pass<false, 1>(L0, dp, a, b, L0.macro2, tau, U0, q & 1, st, st, ev0, ev1);
             hipLaunchKernelGGL((k_march_copy<2>), dim3((unsigned)((dp.nbody + 3) / 4)), dim3(256), 0, st, march_params(L0, a, b, L0.macro2, dp.body, dp.nbody, tau, 1.0f / tau, U0, q & 1));
             step_columns<float, 3>(a, b, L0.macro, L0.mask, L0.tiles, L0.tpc, L0.g, 0, nx, tau, U0, false, q & 1, st);
         }
