@@ -11,7 +11,8 @@ run, one --pmc WRITE_SIZE run) into the files kept under profiles/:
 
 HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) x 1024 x 2 on gfx950 (the counter tallies 128-B requests
 at 64 B for wide coalesced reads), WRITE_SIZE (KB) x 1024; the two counters do not fit one pass, hence two runs.
-One "launch" of the marching path = k_march<..., false, ...> (non-emitting pass) + the k_halo_rows launch before it.
+One "launch" of the marching path = k_march<false, FD> (non-emitting pass) + the k_halo_from_seams launch before it
+(the first pass after an init / a single step builds its halo table with k_halo_rows instead: once per run, not counted).
 """
 import csv
 import datetime
@@ -66,7 +67,7 @@ def main():
         wv = wr.get(k, {}).get("WRITE_SIZE")
         rows.append([k, f, wv])
         if march:
-            use = (k.startswith("wt::k_march<true,false") or k.startswith("wt::k_halo_rows"))
+            use = (k.startswith("wt::k_march<false,") or k.startswith("wt::k_halo_from_seams"))
         else:
             use = k.startswith("wt::k_step<") and ",false," in k
         if use:
@@ -83,7 +84,7 @@ def main():
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[key] = {
         "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
-        "kernel": ("one pass = wt::k_halo_rows + wt::k_march<true,false,...> (TWO steps)" if march else "wt::k_step<float,false,...> (non-emitting step)"),
+        "kernel": ("one pass = wt::k_halo_from_seams + wt::k_march<false,FD> (TWO steps)" if march else "wt::k_step<float,false,...> (non-emitting step)"),
         "measured": datetime.date.today().isoformat() + ", rocprofv3 --pmc on one MI355X box of the gpurun pool, `python bench.py` default workload, "
                     "separate passes for FETCH_SIZE and WRITE_SIZE (not the run that prints the bench line)",
         "source": f"profiles/{tag}_pmc_traffic.csv: FETCH_SIZE KB x1024 x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KB x1024",
