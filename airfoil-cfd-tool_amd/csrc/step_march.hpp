@@ -1,4 +1,11 @@
-// step_march.hpp — TWO lattice steps per launch over the WHOLE lattice, body included (fp32).
+// step_march.hpp — TWO lattice steps per launch over the WHOLE lattice, body included.
+//
+// Templated on the element type T and the sites per lane S (vector of S * sizeof(T) bytes per lane and direction):
+//   <float, 4>  16-byte vectors, 256-row windows — wide fp32 lattices (the bench configuration);
+//   <double, 2> 16-byte vectors, 128-row windows — fp64 lattices;
+//   <float, 2>   8-byte vectors, 128-row windows — narrow fp32 lattices (column slabs), where 256-row windows give too
+//               few units to fill the chip.
+// Below, "256 rows" stands for WIN = 64 * S.
 //
 // A wave owns a WINDOW of 256 rows (j, the fast axis) and marches along a CHUNK of columns (i).
 // Per iteration it (1) requests the 9 streamed input vectors of column c+2 (software prefetch),
@@ -44,18 +51,26 @@
 
 namespace wt {
 
-static constexpr int MARCH_WIN = 256;            // window height = window pitch
 static constexpr int MARCH_MAX_CHUNK = 60;       // class bytes of columns ia-1 .. ib+1 must fit one wave
 
 enum : uint8_t { WC_FAST = 0, WC_GENERAL = 1, WC_SOLID = 2 };
 
-static inline int march_nwin(int ny) { return (ny + MARCH_WIN - 1) / MARCH_WIN; }
+// window height = window pitch = 64 lanes x S sites
+static inline int march_nwin(int ny, int win) { return (ny + win - 1) / win; }
+
+// collision for either element type: fp32 with the division selected by FD (d2q9.hpp), fp64 always IEEE
+template <typename T, int FD>
+__device__ __forceinline__ void collide_t(const T (&fin)[9], const FastDiv &fdv, T tau, T (&fo)[9], T &rho, T &ux, T &uy)
+{
+    if constexpr (sizeof(T) == 4) collide_fd<FD>(fin, fdv, fo, rho, ux, uy);
+    else collide<T>(fin, tau, fo, rho, ux, uy);
+}
 
 // ------------------------------------------------------------------------------------------------
 // once per mask upload
 // ------------------------------------------------------------------------------------------------
 // wcls[w * ld + (x + 1)], x = -1 .. nxl (the two extra columns are FAST), ld = nxl + 2
-__global__ __launch_bounds__(256) void k_classify_windows(const uint8_t *__restrict__ mask, uint8_t *__restrict__ wcls, Geom g, int nwin)
+__global__ __launch_bounds__(256) void k_classify_windows(const uint8_t *__restrict__ mask, uint8_t *__restrict__ wcls, Geom g, int nwin, int win)
 {
     const int lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -64,14 +79,14 @@ __global__ __launch_bounds__(256) void k_classify_windows(const uint8_t *__restr
     const int w = (int)(tile / ld), x = (int)(tile % ld) - 1;
     uint8_t cls = WC_FAST;
     if (x >= 0 && x < g.nxl) {
-        const int j0 = w * MARCH_WIN;
+        const int j0 = w * win;
         const uint8_t *m = mask + g.pitch;
         int nb = 0, own_all = 1;
-        for (int jj = j0 - 1 + lane; jj <= j0 + 256; jj += 64) {
+        for (int jj = j0 - 1 + lane; jj <= j0 + win; jj += 64) {
             if (jj < 0 || jj >= g.ny) continue;
             const int a = m[(long)(x - 1) * g.pitch + jj], b = m[(long)x * g.pitch + jj], c = m[(long)(x + 1) * g.pitch + jj];
             nb |= a | b | c;
-            if (jj >= j0 && jj < j0 + 256) own_all &= (b != 0);
+            if (jj >= j0 && jj < j0 + win) own_all &= (b != 0);
         }
         const bool any_nb = __ballot(nb != 0) != 0ULL;
         const bool all_own = __ballot(own_all == 0) == 0ULL;
@@ -103,14 +118,14 @@ __global__ __launch_bounds__(256) void k_bounce_codes(const uint8_t *__restrict_
 // fluid: not solid, no solid neighbour, not on an inlet / outlet column or the top row.  The halo kernels then read one
 // coalesced byte instead of four scattered mask / code bytes per thread.
 __global__ __launch_bounds__(256) void k_seam_flags(const uint8_t *__restrict__ mask, const uint8_t *__restrict__ bcode, uint8_t *__restrict__ seam_plain,
-                                                    Geom g, int nwin)
+                                                    Geom g, int nwin, int win)
 {
     const long total = (long)(nwin - 1) * g.nxl;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int x = (int)(t % g.nxl);
     const int b = 1 + (int)(t / g.nxl);
-    const int j = MARCH_WIN * b - 1;
+    const int j = win * b - 1;
     const uint8_t *m = mask + g.pitch;
     const long c = (long)x * g.pitch + j;
     const int gi = x + g.gi0;
@@ -123,10 +138,10 @@ __global__ __launch_bounds__(256) void k_seam_flags(const uint8_t *__restrict__ 
 // once per pass: the halo table
 // ------------------------------------------------------------------------------------------------
 // One lattice site, step 1 only, every branch of STEP_FS main() (html:283-360) in the reference's order —
-// the arithmetic of site_general (kernels.hpp) with the relaxation of collide_fd.
-template <int FD>
-__device__ __forceinline__ void site_step1(const float *__restrict__ s, const uint8_t *__restrict__ m, const Geom &g, int i, int j,
-                                           const FastDiv &fdv, float U0, float (&out)[9])
+// the arithmetic of site_general (kernels.hpp) with the relaxation of collide_t.
+template <typename T, int FD>
+__device__ __forceinline__ void site_step1(const T *__restrict__ s, const uint8_t *__restrict__ m, const Geom &g, int i, int j,
+                                           const FastDiv &fdv, T tau, T U0, T (&out)[9])
 {
     const long c = (long)i * g.pitch + j;
     const int gi = i + g.gi0;
@@ -137,106 +152,110 @@ __device__ __forceinline__ void site_step1(const float *__restrict__ s, const ui
 #pragma unroll
         for (int k = 0; k < 9; k++) out[k] = s[k * g.plane + c - g.pitch];
     } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
-        feq_all(1.0f, U0, 0.0f, out);
+        feq_all<T>(T(1), U0, T(0), out);
     } else {                                                       // html:324-359 interior fluid
-        float fin[9], rho, ux, uy;
+        T fin[9], rho, ux, uy;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
             fin[k] = m[src] ? s[opp_of(k) * g.plane + c] : s[k * g.plane + src];
         }
-        collide_fd<FD>(fin, fdv, out, rho, ux, uy);
+        collide_t<T, FD>(fin, fdv, tau, out, rho, ux, uy);
     }
 }
 
-// H[(b * (nxl+2) + x + 1) * 8 + ...], seam b = 1 .. nwin-1 lies between rows 256b-1 and 256b:
-//   [0..2] = step-1 populations 2,5,6 of row 256b-1 (they move up into window b),
-//   [4..6] = step-1 populations 4,7,8 of row 256b   (they move down into window b-1).
+// H[(b * (nxl+2) + x + 1) * 8 + ...], seam b = 1 .. nwin-1 lies between rows WIN*b-1 and WIN*b:
+//   [0..2] = step-1 populations 2,5,6 of row WIN*b-1 (they move up into window b),
+//   [4..6] = step-1 populations 4,7,8 of row WIN*b   (they move down into window b-1).
 // One thread per (seam, column) computes both rows.  Plain fluid sites (no solid neighbour, interior column — the
-// bounce codes say so) take nine 16-byte loads: rows 256b-2 .. 256b+1 of each direction's upstream column hold every
+// seam flags say so) take nine 4-element loads: rows WIN*b-2 .. WIN*b+1 of each direction's upstream column hold every
 // input of the two sites; anything else falls back to site_step1.  The loads are a gather (neighbouring threads are
-// one column = pitch * 4 bytes apart); that, not the arithmetic, is this kernel's cost.
-template <int FD>
-__global__ __launch_bounds__(256) void k_halo_rows(const float *__restrict__ fs, const uint8_t *__restrict__ mask, const uint8_t *__restrict__ seam_plain,
-                                                   float *__restrict__ halo, Geom g, int nwin, FastDiv fdv, float U0)
+// one column = pitch elements apart); that, not the arithmetic, is this kernel's cost.
+template <typename T, int FD>
+__global__ __launch_bounds__(256) void k_halo_rows(const T *__restrict__ fs, const uint8_t *__restrict__ mask, const uint8_t *__restrict__ seam_plain,
+                                                   T *__restrict__ halo, Geom g, int nwin, int win, FastDiv fdv, T tau, T U0)
 {
     const long total = (long)(nwin - 1) * g.nxl;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    // neighbouring threads take the seams of ONE column, 1 KiB apart (neighbouring columns, pitch * 4 bytes apart, measured
-    // the same: the kernel is bound by the rate of scattered 64-byte fetches, ~130 MB of them per 4096^2 lattice)
+    // neighbouring threads take the seams of ONE column, one window apart (neighbouring columns, a pitch apart, measured
+    // the same: the kernel is bound by the rate of scattered 64-byte fetches, ~130 MB of them per 4096^2 fp32 lattice)
     const int b = 1 + (int)(t % (nwin - 1));
     const int x = (int)(t / (nwin - 1));
-    const int j = MARCH_WIN * b - 1;                 // rows j (below the seam) and j + 1 (above it)
+    const int j = win * b - 1;                       // rows j (below the seam) and j + 1 (above it)
     if (j >= g.ny) return;
-    const float *s = fs + g.pitch;
+    const T *s = fs + g.pitch;
     const uint8_t *m = mask + g.pitch;
     const long c = (long)x * g.pitch + j;
-    float lo[9], hi[9];
+    T lo[9], hi[9];
     const bool two = (j + 1 < g.ny);
     const bool plain = seam_plain[(long)(b - 1) * g.nxl + x] != 0;
     if (plain) {
-        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-        float a[9], d[9], rho, ux, uy;
+        typedef T q4u __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+        T a[9], d[9], rho, ux, uy;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const f4u q = *reinterpret_cast<const f4u *>(s + k * g.plane + c - (long)ex_of(k) * g.pitch - 1);     // rows j-1 .. j+2
+            const q4u q = *reinterpret_cast<const q4u *>(s + k * g.plane + c - (long)ex_of(k) * g.pitch - 1);     // rows j-1 .. j+2
             a[k] = q[1 - ey_of(k)];      // input of row j
             d[k] = q[2 - ey_of(k)];      // input of row j+1
         }
-        collide_fd<FD>(a, fdv, lo, rho, ux, uy);
-        collide_fd<FD>(d, fdv, hi, rho, ux, uy);
+        collide_t<T, FD>(a, fdv, tau, lo, rho, ux, uy);
+        collide_t<T, FD>(d, fdv, tau, hi, rho, ux, uy);
     } else {
-        site_step1<FD>(s, m, g, x, j, fdv, U0, lo);
-        if (two) site_step1<FD>(s, m, g, x, j + 1, fdv, U0, hi);
-        else { for (int k = 0; k < 9; k++) hi[k] = 0.0f; }
+        site_step1<T, FD>(s, m, g, x, j, fdv, tau, U0, lo);
+        if (two) site_step1<T, FD>(s, m, g, x, j + 1, fdv, tau, U0, hi);
+        else { for (int k = 0; k < 9; k++) hi[k] = T(0); }
     }
-    float4 *rec = reinterpret_cast<float4 *>(halo + ((long)b * (g.nxl + 2) + x + 1) * 8);
-    rec[0] = make_float4(lo[2], lo[5], lo[6], 0.0f);
-    rec[1] = make_float4(hi[4], hi[7], hi[8], 0.0f);
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    t4 *rec = reinterpret_cast<t4 *>(halo + ((long)b * (g.nxl + 2) + x + 1) * 8);
+    rec[0] = t4{lo[2], lo[5], lo[6], T(0)};
+    rec[1] = t4{hi[4], hi[7], hi[8], T(0)};
 }
 
 // The same table from the seam buffer S that the PREVIOUS marching pass wrote beside the lattice it produced (valid
-// only then: the library tracks it).  Neighbouring threads read neighbouring 192-byte records: coalesced, 13 MB instead
+// only then: the library tracks it).  Neighbouring threads read neighbouring 48-element records: coalesced, 13 MB instead
 // of a 130 MB gather.  Sites near the body / on the inlet and outlet columns fall back to site_step1 on the lattice.
-template <int FD>
-__global__ __launch_bounds__(256) void k_halo_from_seams(const float *__restrict__ fs, const float *__restrict__ seams, const uint8_t *__restrict__ mask,
-                                                         const uint8_t *__restrict__ seam_plain, float *__restrict__ halo, Geom g, int nwin, FastDiv fdv, float U0)
+template <typename T, int FD>
+__global__ __launch_bounds__(256) void k_halo_from_seams(const T *__restrict__ fs, const T *__restrict__ seams, const uint8_t *__restrict__ mask,
+                                                         const uint8_t *__restrict__ seam_plain, T *__restrict__ halo, Geom g, int nwin, int win,
+                                                         FastDiv fdv, T tau, T U0)
 {
     const long total = (long)(nwin - 1) * g.nxl;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
     const int x = (int)(t % g.nxl);
     const int b = 1 + (int)(t / g.nxl);
-    const int j = MARCH_WIN * b - 1;
+    const int j = win * b - 1;
     if (j >= g.ny) return;
-    const float *s = fs + g.pitch;
+    const T *s = fs + g.pitch;
     const uint8_t *m = mask + g.pitch;
-    float lo[9], hi[9];
+    T lo[9], hi[9];
     const bool two = (j + 1 < g.ny);
     const bool plain = seam_plain[t] != 0;
     if (plain) {
-        float a[9], d[9], rho, ux, uy;
-        const float *rec = seams + ((long)b * (g.nxl + 2) + x + 1) * 48;
+        T a[9], d[9], rho, ux, uy;
+        const T *rec = seams + ((long)b * (g.nxl + 2) + x + 1) * 48;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const float *r = rec - (long)ex_of(k) * 48 + 2 * k;
-            const float2 below = *reinterpret_cast<const float2 *>(r);            // rows 256b-2, 256b-1
-            const float2 above = *reinterpret_cast<const float2 *>(r + 24);       // rows 256b, 256b+1
-            const float q[4] = {below.x, below.y, above.x, above.y};
-            a[k] = q[1 - ey_of(k)];      // input of row 256b-1
-            d[k] = q[2 - ey_of(k)];      // input of row 256b
+            const T *r = rec - (long)ex_of(k) * 48 + 2 * k;
+            typedef T t2 __attribute__((ext_vector_type(2)));
+            const t2 below = *reinterpret_cast<const t2 *>(r);           // rows WIN*b-2, WIN*b-1
+            const t2 above = *reinterpret_cast<const t2 *>(r + 24);      // rows WIN*b, WIN*b+1
+            const T q[4] = {below[0], below[1], above[0], above[1]};
+            a[k] = q[1 - ey_of(k)];      // input of row WIN*b-1
+            d[k] = q[2 - ey_of(k)];      // input of row WIN*b
         }
-        collide_fd<FD>(a, fdv, lo, rho, ux, uy);
-        collide_fd<FD>(d, fdv, hi, rho, ux, uy);
+        collide_t<T, FD>(a, fdv, tau, lo, rho, ux, uy);
+        collide_t<T, FD>(d, fdv, tau, hi, rho, ux, uy);
     } else {
-        site_step1<FD>(s, m, g, x, j, fdv, U0, lo);
-        if (two) site_step1<FD>(s, m, g, x, j + 1, fdv, U0, hi);
-        else { for (int k = 0; k < 9; k++) hi[k] = 0.0f; }
+        site_step1<T, FD>(s, m, g, x, j, fdv, tau, U0, lo);
+        if (two) site_step1<T, FD>(s, m, g, x, j + 1, fdv, tau, U0, hi);
+        else { for (int k = 0; k < 9; k++) hi[k] = T(0); }
     }
-    float4 *out = reinterpret_cast<float4 *>(halo + ((long)b * (g.nxl + 2) + x + 1) * 8);
-    out[0] = make_float4(lo[2], lo[5], lo[6], 0.0f);
-    out[1] = make_float4(hi[4], hi[7], hi[8], 0.0f);
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    t4 *out = reinterpret_cast<t4 *>(halo + ((long)b * (g.nxl + 2) + x + 1) * 8);
+    out[0] = t4{lo[2], lo[5], lo[6], T(0)};
+    out[1] = t4{hi[4], hi[7], hi[8], T(0)};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -245,55 +264,103 @@ __global__ __launch_bounds__(256) void k_halo_from_seams(const float *__restrict
 struct MarchUnit { int ia, ib, w, flags; };      // marched columns [ia, ib), window; flags bit 0: emit the outlet column ib with column ib-1
 enum { MU_OUTLET_AFTER = 1 };
 
+template <typename T>
 struct MarchParams {
-    const float *fs;
-    float *fd;
-    float *macro;
+    const T *fs;
+    T *fd;
+    T *macro;
     const uint8_t *mask;       // padded byte mask (column -1 first)
     const uint8_t *bcode;      // bounce codes, column 0 first
     const uint8_t *wcls;       // window-tile classes [nwin][nxl + 2]
-    const float *halo;         // H[nwin + 1][nxl + 2][8], see k_halo_rows
-    float *seams;              // S[nwin + 1][nxl + 2][2][24]: the rows around every window seam of the DESTINATION lattice, see k_halo_from_seams
+    const T *halo;             // H[nwin + 1][nxl + 2][8], see k_halo_rows
+    T *seams;                  // S[nwin + 1][nxl + 2][2][24]: the rows around every window seam of the DESTINATION lattice, see k_halo_from_seams
     const MarchUnit *units;
     int nunits;
     Geom g;
     unsigned lat_bytes;        // bytes of one lattice (9 planes) — below 4 GiB
     int nwin_total;            // windows per column
-    FastDiv fdv;
-    float U0;
+    FastDiv fdv;               // fp32: tau and RN(1/tau)
+    T tau;
+    T U0;
     int rev;
 };
 
-typedef Vec<float> V4;
+// S consecutive rows of one column and direction, held by one lane
+template <typename T, int S> struct MV { T v[S]; };
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+template <int BYTES> struct RawOf;
+template <> struct RawOf<16> { typedef u4v type; };
+template <> struct RawOf<8> { typedef u2v type; };
 
-__device__ __forceinline__ V4 v4_splat(float x) { V4 r; r.v[0] = x; r.v[1] = x; r.v[2] = x; r.v[3] = x; return r; }
+template <typename T, int S> __device__ __forceinline__ MV<T, S> mv_splat(T x)
+{
+    MV<T, S> r;
+#pragma unroll
+    for (int v = 0; v < S; v++) r.v[v] = x;
+    return r;
+}
 
 // value at j-1 / j+1 taken from the neighbouring lane
 // (lane 0 / lane 63 take the value of the row outside the window from the halo table: `edge`, wave-uniform)
-__device__ __forceinline__ V4 m_below(const V4 &r, int lane, float edge) { V4 o; const float n = lane_up(r.v[3]); o.v[0] = lane == 0 ? edge : n; o.v[1] = r.v[0]; o.v[2] = r.v[1]; o.v[3] = r.v[2]; return o; }
-__device__ __forceinline__ V4 m_above(const V4 &r, int lane, float edge) { V4 o; const float n = lane_down(r.v[0]); o.v[0] = r.v[1]; o.v[1] = r.v[2]; o.v[2] = r.v[3]; o.v[3] = lane == 63 ? edge : n; return o; }
+template <typename T, int S> __device__ __forceinline__ MV<T, S> m_below(const MV<T, S> &r, int lane, T edge)
+{
+    MV<T, S> o;
+    const T n = lane_up(r.v[S - 1]);
+    o.v[0] = lane == 0 ? edge : n;
+#pragma unroll
+    for (int v = 1; v < S; v++) o.v[v] = r.v[v - 1];
+    return o;
+}
+template <typename T, int S> __device__ __forceinline__ MV<T, S> m_above(const MV<T, S> &r, int lane, T edge)
+{
+    MV<T, S> o;
+    const T n = lane_down(r.v[0]);
+#pragma unroll
+    for (int v = 0; v < S - 1; v++) o.v[v] = r.v[v + 1];
+    o.v[S - 1] = lane == 63 ? edge : n;
+    return o;
+}
 
-// buffer addressing: rsrc = whole lattice; voff = the lane's byte offset (j0 * 4, loop-invariant);
+// buffer addressing: rsrc = whole lattice; voff = the lane's byte offset (j0 * sizeof(T), loop-invariant);
 // soff = scalar byte offset of (plane, column, row shift)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t march_rsrc(const void *p, unsigned bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ V4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+template <typename T, int S>
+__device__ __forceinline__ MV<T, S> bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-    const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);     // aux 2 = nt (read once per pass)
-    V4 o;
-    o.v[0] = __uint_as_float(x.x); o.v[1] = __uint_as_float(x.y); o.v[2] = __uint_as_float(x.z); o.v[3] = __uint_as_float(x.w);
+    MV<T, S> o;
+    if constexpr (S * sizeof(T) == 16) {
+        const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);     // aux 2 = nt (read once per pass)
+        __builtin_memcpy(&o, &x, 16);
+    } else {
+        const u2v x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2);
+        __builtin_memcpy(&o, &x, 8);
+    }
     return o;
 }
-__device__ __forceinline__ u4v bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const V4 &v)
+// returns the raw data registers of the store, for store_data_fence()
+template <typename T, int S>
+__device__ __forceinline__ typename RawOf<S * sizeof(T)>::type bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const MV<T, S> &v)
 {
-    u4v x;
-    x.x = __float_as_uint(v.v[0]); x.y = __float_as_uint(v.v[1]); x.z = __float_as_uint(v.v[2]); x.w = __float_as_uint(v.v[3]);
-    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, WT_STORE_AUX);
-    return x;                                                                  // for store_data_fence()
+    typename RawOf<S * sizeof(T)>::type x;
+    __builtin_memcpy(&x, &v, S * sizeof(T));
+    if constexpr (S * sizeof(T) == 16) __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, WT_STORE_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, WT_STORE_AUX);
+    return x;
+}
+// two elements (one seam slot)
+template <typename T>
+__device__ __forceinline__ typename RawOf<2 * sizeof(T)>::type bstore2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, T a, T b)
+{
+    typename RawOf<2 * sizeof(T)>::type x;
+    const T ab[2] = {a, b};
+    __builtin_memcpy(&x, ab, 2 * sizeof(T));
+    if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+    return x;
 }
 // STORE-DATA HAZARD (measured on MI355X, ROCm 7.2): a buffer_store_dwordx4 whose soffset is an SGPR reads its data
 // VGPRs a little after it issues.  A VALU instruction right behind it that overwrites one of them can win that race for
@@ -302,107 +369,124 @@ __device__ __forceinline__ u4v bstore(__amdgpu_buffer_rsrc_t r, unsigned voff, u
 // and not on every run).  hipcc pads this hazard only for stores WITHOUT a register soffset (LLVM GCNHazardRecognizer::
 // createsVALUHazard), so the pad is ours: the asm keeps every data tuple of a store group live up to this point and
 // its `s_nop 1` gives the two wait states after the group's last store.  tools/check_store_hazard.py verifies the
-// generated ISA (run by tests/test_build_hazards.py).
-__device__ __forceinline__ void store_data_fence(const u4v (&d)[12], int n)
+// generated ISA (run by tests/test_build_hazards.py).  (8-byte stores have no such hazard; the fence is harmless there.)
+template <typename R>
+__device__ __forceinline__ void store_data_fence(const R (&d)[12], int n)
 {
     if (n == 12)
         asm volatile("s_nop 1" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]), "v"(d[9]), "v"(d[10]), "v"(d[11]));
     else
         asm volatile("s_nop 1" ::"v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]));
 }
-__device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b)
+template <typename R>
+__device__ __forceinline__ void store_data_fence2(const R &a, const R &b)
 {
-    u2v x;
-    x.x = __float_as_uint(a); x.y = __float_as_uint(b);
-    __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+    if constexpr (sizeof(R) == 16) asm volatile("s_nop 1" ::"v"(a), "v"(b));
 }
 
+template <typename T, int S>
 struct MarchAddr {
     __amdgpu_buffer_rsrc_t rs, rd, rm;   // source lattice, destination lattice, macro planes
-    unsigned voff;                       // j0 * 4
+    unsigned voff;                       // j0 * sizeof(T)
     unsigned voff_st;                    // the same for stores; lanes beyond the last row: out of range (dropped by the buffer check)
     __amdgpu_buffer_rsrc_t rseam;        // seam buffer S
     unsigned voff_lo, voff_hi;           // lanes 0..11: byte offsets of their slot in the two half records this window writes; other lanes: out of range
-    float *lds_w, *lds_r;                // this lane's LDS address for staging (write) and for the transposed read-back
+    T *lds_w, *lds_r;                    // this lane's LDS address for staging (write) and for the transposed read-back
     int lane;
     unsigned P4, pitch4, mp4;            // plane / column / macro-plane strides in bytes
 };
 
 // byte offset of (plane k, local column col, row shift dj) from the lattice base (one pad column in front)
-__device__ __forceinline__ unsigned lat_off(const MarchAddr &a, int k, int col, int dj)
+template <typename T, int S>
+__device__ __forceinline__ unsigned lat_off(const MarchAddr<T, S> &a, int k, int col, int dj)
 {
-    return (unsigned)k * a.P4 + (unsigned)(col + 1) * a.pitch4 + (unsigned)(dj * 4);
+    return (unsigned)k * a.P4 + (unsigned)(col + 1) * a.pitch4 + (unsigned)(dj * (int)sizeof(T));
 }
 
 // the nine streamed (pulled) input vectors of column `col`
-__device__ __forceinline__ void march_load_stream(const MarchAddr &a, int col, V4 (&fin)[9])
+template <typename T, int S>
+__device__ __forceinline__ void march_load_stream(const MarchAddr<T, S> &a, int col, MV<T, S> (&fin)[9])
 {
-    fin[0] = bload(a.rs, a.voff, lat_off(a, 0, col, 0));
-    fin[1] = bload(a.rs, a.voff, lat_off(a, 1, col - 1, 0));
-    fin[3] = bload(a.rs, a.voff, lat_off(a, 3, col + 1, 0));
-    fin[2] = bload(a.rs, a.voff, lat_off(a, 2, col, -1));
-    fin[5] = bload(a.rs, a.voff, lat_off(a, 5, col - 1, -1));
-    fin[6] = bload(a.rs, a.voff, lat_off(a, 6, col + 1, -1));
-    fin[4] = bload(a.rs, a.voff, lat_off(a, 4, col, 1));
-    fin[7] = bload(a.rs, a.voff, lat_off(a, 7, col + 1, 1));
-    fin[8] = bload(a.rs, a.voff, lat_off(a, 8, col - 1, 1));
+    fin[0] = bload<T, S>(a.rs, a.voff, lat_off(a, 0, col, 0));
+    fin[1] = bload<T, S>(a.rs, a.voff, lat_off(a, 1, col - 1, 0));
+    fin[3] = bload<T, S>(a.rs, a.voff, lat_off(a, 3, col + 1, 0));
+    fin[2] = bload<T, S>(a.rs, a.voff, lat_off(a, 2, col, -1));
+    fin[5] = bload<T, S>(a.rs, a.voff, lat_off(a, 5, col - 1, -1));
+    fin[6] = bload<T, S>(a.rs, a.voff, lat_off(a, 6, col + 1, -1));
+    fin[4] = bload<T, S>(a.rs, a.voff, lat_off(a, 4, col, 1));
+    fin[7] = bload<T, S>(a.rs, a.voff, lat_off(a, 7, col + 1, 1));
+    fin[8] = bload<T, S>(a.rs, a.voff, lat_off(a, 8, col - 1, 1));
 }
 
-// the nine populations of the sites of column `col` themselves
-__device__ __forceinline__ void march_load_own(const MarchAddr &a, int col, V4 (&own)[9])
+// S mask / bounce-code bytes of a lane's sites, site v in bits 8v .. 8v+7
+template <int S> __device__ __forceinline__ uint32_t load_site_bytes(const uint8_t *p)
 {
-#pragma unroll
-    for (int k = 0; k < 9; k++) own[k] = bload(a.rs, a.voff, lat_off(a, k, col, 0));
+    if constexpr (S == 4) return *reinterpret_cast<const uint32_t *>(p);
+    else return *reinterpret_cast<const uint16_t *>(p);
 }
 
-// collide 4 sites per lane; one wave-uniform decision between the fast and the IEEE division by tau
-template <int FD>
-__device__ __forceinline__ void march_collide4(const V4 (&fin)[9], const FastDiv &fdv, V4 (&o)[9], V4 &rho4, V4 &ux4, V4 &uy4)
+// collide S sites per lane; fp32: one wave-uniform decision between the fast and the IEEE division by tau
+template <typename T, int S, int FD>
+__device__ __forceinline__ void march_collide_sites(const MV<T, S> (&fin)[9], const FastDiv &fdv, T tau, MV<T, S> (&o)[9], MV<T, S> &rho4, MV<T, S> &ux4,
+                                                    MV<T, S> &uy4)
 {
-    float r[4], u[4], w[4], s2[4];
-    bool safe = true;
+    if constexpr (sizeof(T) == 4) {
+        float r[S], u[S], w[S], s2[S];
+        bool safe = true;
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-        float a[9];
-        bool sv;
+        for (int v = 0; v < S; v++) {
+            float a[9];
+            bool sv;
 #pragma unroll
-        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
-        collide_head(a, r[v], u[v], w[v], s2[v], sv);
-        safe = safe && sv;
+            for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+            collide_head(a, r[v], u[v], w[v], s2[v], sv);
+            safe = safe && sv;
+        }
+        const bool fast = (FD == 2) || (FD == 1 && __ballot(!safe) == 0ULL);
+#pragma unroll
+        for (int v = 0; v < S; v++) {
+            float a[9], f[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+            if (FD != 0 && fast) collide_tail<true>(a, fdv, r[v], u[v], w[v], s2[v], f);
+            else collide_tail<false>(a, fdv, r[v], u[v], w[v], s2[v], f);
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k].v[v] = f[k];
+            rho4.v[v] = r[v]; ux4.v[v] = u[v]; uy4.v[v] = w[v];
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < S; v++) {
+            T a[9], f[9], r, u, w;
+#pragma unroll
+            for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+            collide<T>(a, tau, f, r, u, w);
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k].v[v] = f[k];
+            rho4.v[v] = r; ux4.v[v] = u; uy4.v[v] = w;
+        }
     }
-    const bool fast = (FD == 2) || (FD == 1 && __ballot(!safe) == 0ULL);
-#pragma unroll
-    for (int v = 0; v < 4; v++) {
-        float a[9], f[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
-        if (FD != 0 && fast) collide_tail<true>(a, fdv, r[v], u[v], w[v], s2[v], f);
-        else collide_tail<false>(a, fdv, r[v], u[v], w[v], s2[v], f);
-#pragma unroll
-        for (int k = 0; k < 9; k++) o[k].v[v] = f[k];
-        rho4.v[v] = r[v]; ux4.v[v] = u[v]; uy4.v[v] = w[v];
-    }
 }
 
-template <int FD, bool WANT_MACRO>
-__device__ __forceinline__ void march_collide(const V4 (&fin)[9], const FastDiv &fdv, V4 (&G)[9], V4 (&mac)[3])
+template <typename T, int S, int FD, bool WANT_MACRO>
+__device__ __forceinline__ void march_collide(const MV<T, S> (&fin)[9], const FastDiv &fdv, T tau, MV<T, S> (&G)[9], MV<T, S> (&mac)[3])
 {
-    V4 rho4, ux4, uy4;
-    march_collide4<FD>(fin, fdv, G, rho4, ux4, uy4);
+    MV<T, S> rho4, ux4, uy4;
+    march_collide_sites<T, S, FD>(fin, fdv, tau, G, rho4, ux4, uy4);
     if (WANT_MACRO) { mac[0] = rho4; mac[1] = ux4; mac[2] = uy4; }
 }
 
 // rows 0 and NY-1 carry the far-field populations (html:314-322); only called for windows that hold one of them
-template <bool WANT_MACRO>
-__device__ __forceinline__ void march_far_rows(int j0, int ny, float U0, const float (&feq0)[9], V4 (&G)[9], V4 (&mac)[3])
+template <typename T, int S, bool WANT_MACRO>
+__device__ __forceinline__ void march_far_rows(int j0, int ny, T U0, const T (&feq0)[9], MV<T, S> (&G)[9], MV<T, S> (&mac)[3])
 {
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
+    for (int v = 0; v < S; v++) {
         const int j = j0 + v;
         const bool far = (j == 0) || (j == ny - 1);
 #pragma unroll
         for (int k = 0; k < 9; k++) G[k].v[v] = far ? feq0[k] : G[k].v[v];
-        if (WANT_MACRO) { mac[0].v[v] = far ? 1.0f : mac[0].v[v]; mac[1].v[v] = far ? U0 : mac[1].v[v]; mac[2].v[v] = far ? 0.0f : mac[2].v[v]; }
+        if (WANT_MACRO) { mac[0].v[v] = far ? T(1) : mac[0].v[v]; mac[1].v[v] = far ? U0 : mac[1].v[v]; mac[2].v[v] = far ? T(0) : mac[2].v[v]; }
     }
 }
 
@@ -410,66 +494,67 @@ __device__ __forceinline__ void march_far_rows(int j0, int ny, float U0, const f
 // direction k of a site takes the site's OWN population opp(k) where the bounce code has bit k-1 set.
 // `own(k)` yields the vector of the sites' own populations of direction k (step 1: an aligned load,
 // step 2: the step-1 vector of column c held in registers); one vector is live at a time.
-template <typename OWN>
-__device__ __forceinline__ void march_bounce(V4 (&fin)[9], uint32_t code4, OWN own)
+template <typename T, int S, typename OWN>
+__device__ __forceinline__ void march_bounce(MV<T, S> (&fin)[9], uint32_t code4, OWN own)
 {
 #pragma unroll
     for (int k = 1; k < 9; k++) {
-        const V4 o = own(opp_of(k));
+        const MV<T, S> o = own(opp_of(k));
 #pragma unroll
-        for (int v = 0; v < 4; v++) fin[k].v[v] = ((code4 >> (8 * v + k - 1)) & 1u) ? o.v[v] : fin[k].v[v];
+        for (int v = 0; v < S; v++) fin[k].v[v] = ((code4 >> (8 * v + k - 1)) & 1u) ? o.v[v] : fin[k].v[v];
     }
 }
 
 // GENERAL tile, the collision itself.  `fin` went through march_bounce with code 0xFF on solid sites, i.e. a solid
 // site's fin[k] already IS its own population opp(k) — the value the reference stores for it (html:287-294) — so the
 // solid select needs no further loads.  Reference order: solid, far field (html:314-322), interior (html:335-359).
-template <int FD, bool WANT_MACRO>
-__device__ __forceinline__ void march_collide_general(const V4 (&fin)[9], uint32_t solid4, int j0, int ny, const FastDiv &fdv, float U0,
-                                                      const float (&feq0)[9], V4 (&G)[9], V4 (&mac)[3])
+template <typename T, int S, int FD, bool WANT_MACRO>
+__device__ __forceinline__ void march_collide_general(const MV<T, S> (&fin)[9], uint32_t solid4, int j0, int ny, const FastDiv &fdv, T tau, T U0,
+                                                      const T (&feq0)[9], MV<T, S> (&G)[9], MV<T, S> (&mac)[3])
 {
-    V4 o[9], rho4, ux4, uy4;
-    march_collide4<FD>(fin, fdv, o, rho4, ux4, uy4);
+    MV<T, S> o[9], rho4, ux4, uy4;
+    march_collide_sites<T, S, FD>(fin, fdv, tau, o, rho4, ux4, uy4);
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
+    for (int v = 0; v < S; v++) {
         const bool solid = ((solid4 >> (8 * v)) & 0xffu) != 0;
         const int j = j0 + v;
         const bool far = (j == 0) || (j == ny - 1);
 #pragma unroll
         for (int k = 0; k < 9; k++) G[k].v[v] = solid ? fin[k].v[v] : (far ? feq0[k] : o[k].v[v]);
         if (WANT_MACRO) {
-            mac[0].v[v] = (solid || far) ? 1.0f : rho4.v[v];
-            mac[1].v[v] = solid ? 0.0f : (far ? U0 : ux4.v[v]);
-            mac[2].v[v] = (solid || far) ? 0.0f : uy4.v[v];
+            mac[0].v[v] = (solid || far) ? T(1) : rho4.v[v];
+            mac[1].v[v] = solid ? T(0) : (far ? U0 : ux4.v[v]);
+            mac[2].v[v] = (solid || far) ? T(0) : uy4.v[v];
         }
     }
 }
 
 // after the collision: solid sites carry their own populations reversed (html:287-294), macro (1,0,0)
-template <bool WANT_MACRO, typename OWN>
-__device__ __forceinline__ void march_solid(V4 (&G)[9], V4 (&mac)[3], uint32_t solid4, OWN own)
+template <typename T, int S, bool WANT_MACRO, typename OWN>
+__device__ __forceinline__ void march_solid(MV<T, S> (&G)[9], MV<T, S> (&mac)[3], uint32_t solid4, OWN own)
 {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        const V4 o = own(opp_of(k));
+        const MV<T, S> o = own(opp_of(k));
 #pragma unroll
-        for (int v = 0; v < 4; v++) G[k].v[v] = ((solid4 >> (8 * v)) & 0xffu) ? o.v[v] : G[k].v[v];
+        for (int v = 0; v < S; v++) G[k].v[v] = ((solid4 >> (8 * v)) & 0xffu) ? o.v[v] : G[k].v[v];
     }
     if (WANT_MACRO) {
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < S; v++) {
             const bool solid = ((solid4 >> (8 * v)) & 0xffu) != 0;
-            mac[0].v[v] = solid ? 1.0f : mac[0].v[v]; mac[1].v[v] = solid ? 0.0f : mac[1].v[v]; mac[2].v[v] = solid ? 0.0f : mac[2].v[v];
+            mac[0].v[v] = solid ? T(1) : mac[0].v[v]; mac[1].v[v] = solid ? T(0) : mac[1].v[v]; mac[2].v[v] = solid ? T(0) : mac[2].v[v];
         }
     }
 }
 
 // outlet column (html:301-312): macro = moments of the copied populations, not clamped
-__device__ __forceinline__ void march_outlet_macro(const V4 (&q9)[9], V4 (&mac)[3])
+template <typename T, int S>
+__device__ __forceinline__ void march_outlet_macro(const MV<T, S> (&q9)[9], MV<T, S> (&mac)[3])
 {
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-        float q[9], rho, ux, uy;
+    for (int v = 0; v < S; v++) {
+        T q[9], rho, ux, uy;
 #pragma unroll
         for (int k = 0; k < 9; k++) q[k] = q9[k].v[v];
         moments(q, rho, ux, uy);
@@ -481,128 +566,153 @@ __device__ __forceinline__ void march_outlet_macro(const V4 (&q9)[9], V4 (&mac)[
 // the buffer range check drops their stores.  (A divergent `if (row < NY)` around the stores makes hipcc's waitcnt
 // pass merge the "stored" and "not stored" paths and drain vmcnt to 0 at the loop tail — every iteration then waits
 // for its own nine stores to complete before the next one starts.)
-template <bool EMIT>
-__device__ __forceinline__ void march_store(const MarchAddr &a, int col, const V4 (&out)[9], const V4 (&mac)[3])
+template <bool EMIT, typename T, int S>
+__device__ __forceinline__ void march_store(const MarchAddr<T, S> &a, int col, const MV<T, S> (&out)[9], const MV<T, S> (&mac)[3])
 {
-    u4v d[12];
+    typename RawOf<S * sizeof(T)>::type d[12];
 #pragma unroll
-    for (int k = 0; k < 9; k++) d[k] = bstore(a.rd, a.voff_st, lat_off(a, k, col, 0), out[k]);
+    for (int k = 0; k < 9; k++) d[k] = bstore<T, S>(a.rd, a.voff_st, lat_off(a, k, col, 0), out[k]);
     if (EMIT) {
         const unsigned mo = (unsigned)col * a.pitch4;
 #pragma unroll
-        for (int q = 0; q < 3; q++) d[9 + q] = bstore(a.rm, a.voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
+        for (int q = 0; q < 3; q++) d[9 + q] = bstore<T, S>(a.rm, a.voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
     }
     store_data_fence(d, EMIT ? 12 : 9);
     // The two rows on either side of the window seams go, once more, into the seam buffer S (lane 0 holds rows 0,1 — above
-    // seam w; lane 63 rows 254,255 — below seam w+1).  They pass through LDS so that 12 lanes write each half record as 96
-    // contiguous, 32-byte-aligned bytes (whole memory sectors: two-lane 8-byte stores straight from lanes 0 / 63 cost more
+    // seam w; lane 63 the window's last two rows — below seam w+1).  They pass through LDS so that 12 lanes write each half
+    // record as contiguous, sector-aligned bytes (whole memory sectors: two-lane stores straight from lanes 0 / 63 cost more
     // than the table saves — partial sectors are read-modify-written).  Software-pipelined: this call only STAGES the
-    // values (one ds_write_b64 per direction, every lane, no branch: lanes 1..62 hit a scratch slot); seam_fetch() at the
+    // values (one LDS write per direction, every lane, no branch: lanes 1..62 hit a scratch slot); seam_fetch() at the
     // top of the next iteration reads them back transposed and seam_flush() stores them beside that iteration's stores,
     // so no LDS latency is exposed.  The next pass builds its halo table from S with coalesced loads
-    // (k_halo_from_seams) instead of a 130 MB gather (k_halo_rows).
+    // (k_halo_from_seams) instead of a gather (k_halo_rows).
+    typedef T t2 __attribute__((ext_vector_type(2)));
     const bool top = a.lane == 63;
 #pragma unroll
     for (int k = 0; k < 9; k++)
-        *reinterpret_cast<float2 *>(a.lds_w + 2 * k) = make_float2(top ? out[k].v[2] : out[k].v[0], top ? out[k].v[3] : out[k].v[1]);
+        *reinterpret_cast<t2 *>(a.lds_w + 2 * k) = t2{top ? out[k].v[S - 2] : out[k].v[0], top ? out[k].v[S - 1] : out[k].v[1]};
 }
 
 // seam values staged by the previous march_store, transposed: lane k < 9 gets direction k's pair of rows
-struct SeamPair { float2 below, above; };
-__device__ __forceinline__ SeamPair seam_fetch(const MarchAddr &a)
+template <typename T> struct SeamPair { T below[2], above[2]; };
+template <typename T, int S>
+__device__ __forceinline__ SeamPair<T> seam_fetch(const MarchAddr<T, S> &a)
 {
-    SeamPair r;
-    r.below = *reinterpret_cast<const float2 *>(a.lds_r);         // rows 254,255 (staged by lane 63)
-    r.above = *reinterpret_cast<const float2 *>(a.lds_r + 24);    // rows 0,1     (staged by lane 0)
+    typedef T t2 __attribute__((ext_vector_type(2)));
+    SeamPair<T> r;
+    const t2 b = *reinterpret_cast<const t2 *>(a.lds_r);          // the window's last two rows (staged by lane 63)
+    const t2 t = *reinterpret_cast<const t2 *>(a.lds_r + 24);     // rows 0,1                   (staged by lane 0)
+    r.below[0] = b[0]; r.below[1] = b[1]; r.above[0] = t[0]; r.above[1] = t[1];
     return r;
 }
-__device__ __forceinline__ void seam_flush(const MarchAddr &a, int col, const SeamPair &r)
+template <typename T, int S>
+__device__ __forceinline__ void seam_flush(const MarchAddr<T, S> &a, int col, const SeamPair<T> &r)
 {
-    const unsigned so = (unsigned)(col + 1) * 192u;
-    bstore2(a.rseam, a.voff_hi, so, r.below.x, r.below.y);        // -> seam w+1, half 0
-    bstore2(a.rseam, a.voff_lo, so, r.above.x, r.above.y);        // -> seam w,   half 1
+    const unsigned so = (unsigned)(col + 1) * (unsigned)(48 * sizeof(T));
+    const auto d0 = bstore2<T>(a.rseam, a.voff_hi, so, r.below[0], r.below[1]);        // -> seam w+1, half 0
+    const auto d1 = bstore2<T>(a.rseam, a.voff_lo, so, r.above[0], r.above[1]);        // -> seam w,   half 1
+    store_data_fence2(d0, d1);
+}
+
+// wave-uniform value of lane l of a halo-table word
+template <typename T> __device__ __forceinline__ T readlane_t(T x, int l)
+{
+    if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), l));
+    else {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(x), l), hi = __builtin_amdgcn_readlane((unsigned)__double2hiint(x), l);
+        return __hiloint2double((int)hi, (int)lo);
+    }
+}
+template <typename T> __device__ __forceinline__ T halo_load(__amdgpu_buffer_rsrc_t rh, unsigned hoff, unsigned soff)
+{
+    if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, hoff, soff, 0));
+    else {
+        const u2v x = __builtin_amdgcn_raw_buffer_load_b64(rh, hoff, soff, 0);
+        return __hiloint2double((int)x.y, (int)x.x);
+    }
 }
 
 // Step 1 of column x -> G (all nine directions).  `in` holds the streamed inputs of column x (modified in place).
-template <bool BODY, int FD>
-__device__ __forceinline__ void march_step1(const MarchParams &p, const MarchAddr &a, int x, int j0, bool far_win, bool nonfast, bool allsolid,
-                                            const float (&feq0)[9], V4 (&in)[9], V4 (&G)[9])
+template <bool BODY, int FD, typename T, int S>
+__device__ __forceinline__ void march_step1(const MarchParams<T> &p, const MarchAddr<T, S> &a, int x, int j0, bool far_win, bool nonfast, bool allsolid,
+                                            const T (&feq0)[9], MV<T, S> (&in)[9], MV<T, S> (&G)[9])
 {
-    V4 mac[3];
+    MV<T, S> mac[3];
     if (BODY) {
         const Geom &g = p.g;
         const int gi = x + g.gi0;
-        auto own = [&](int k) { return bload(a.rs, a.voff, lat_off(a, k, x, 0)); };
+        auto own = [&](int k) { return bload<T, S>(a.rs, a.voff, lat_off(a, k, x, 0)); };
         if (__builtin_expect(gi <= 0 || gi >= g.nx_g - 1 || nonfast, 0)) {
             // rare paths (scalar branches): inlet / outlet columns, body surface, body interior
             uint32_t solid4 = 0, code4 = 0;
             if (nonfast) {
-                solid4 = *reinterpret_cast<const uint32_t *>(p.mask + (long)(x + 1) * g.pitch + j0);
-                code4 = *reinterpret_cast<const uint32_t *>(p.bcode + (long)x * g.pitch + j0);
+                solid4 = load_site_bytes<S>(p.mask + (long)(x + 1) * g.pitch + j0);
+                code4 = load_site_bytes<S>(p.bcode + (long)x * g.pitch + j0);
             }
             const bool any_solid = __ballot(solid4 != 0) != 0ULL;
             if (gi <= 0) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) G[k] = v4_splat(feq0[k]);
+                for (int k = 0; k < 9; k++) G[k] = mv_splat<T, S>(feq0[k]);
             } else if (gi >= g.nx_g - 1) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) G[k] = bload(a.rs, a.voff, lat_off(a, k, x - 1, 0));
+                for (int k = 0; k < 9; k++) G[k] = bload<T, S>(a.rs, a.voff, lat_off(a, k, x - 1, 0));
             } else if (allsolid) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) G[k] = own(opp_of(k));
                 return;
             } else {
-                march_bounce(in, code4, own);
-                march_collide_general<FD, false>(in, solid4, j0, g.ny, p.fdv, p.U0, feq0, G, mac);
+                march_bounce<T, S>(in, code4, own);
+                march_collide_general<T, S, FD, false>(in, solid4, j0, g.ny, p.fdv, p.tau, p.U0, feq0, G, mac);
                 return;
             }
-            if (any_solid) march_solid<false>(G, mac, solid4, own);      // inlet / outlet columns with solid sites
+            if (any_solid) march_solid<T, S, false>(G, mac, solid4, own);      // inlet / outlet columns with solid sites
             return;
         }
     }
-    march_collide<FD, false>(in, p.fdv, G, mac);
-    if (far_win) march_far_rows<false>(j0, p.g.ny, p.U0, feq0, G, mac);
+    march_collide<T, S, FD, false>(in, p.fdv, p.tau, G, mac);
+    if (far_win) march_far_rows<T, S, false>(j0, p.g.ny, p.U0, feq0, G, mac);
 }
 
 // One unit: marched columns [ia, ib) of window w.  BODY = false: the unit's footprint is plain interior fluid — no
 // class tests, no mask, no inlet / outlet logic, fewer live registers (no spills); BODY = true: everything.
-template <bool BODY, bool EMIT, int FD>
-__device__ __forceinline__ void march_unit(const MarchParams &p, MarchAddr &a, __amdgpu_buffer_rsrc_t rh, unsigned hoff, int ia, int ib, int uflags,
+template <bool BODY, bool EMIT, int FD, typename T, int S>
+__device__ __forceinline__ void march_unit(const MarchParams<T> &p, MarchAddr<T, S> &a, __amdgpu_buffer_rsrc_t rh, unsigned hoff, int ia, int ib, int uflags,
                                            int j0, int lane, bool far_win, unsigned long long nonfast_m, unsigned long long solid_m,
-                                           const float (&feq0)[9])
+                                           const T (&feq0)[9])
 {
+    typedef MV<T, S> V;
     const Geom &g = p.g;
+    constexpr unsigned HREC = 8 * sizeof(T);     // bytes of one halo-table record
 #define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 1)) & 1ULL) != 0)
 #define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 1)) & 1ULL) != 0)
-#define STEP1(x, in, G) march_step1<BODY, FD>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+#define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
 
-    V4 G158m[3];                 // step-1 populations 1,5,8 of column c-1
-    V4 Gc[9];                    // step-1 populations of column c (BODY = false: only 0,2,4 and 1,5,8 stay live)
-    V4 in[9], G[9], mac[3];
+    V G158m[3];                  // step-1 populations 1,5,8 of column c-1
+    V Gc[9];                     // step-1 populations of column c (BODY = false: only 0,2,4 and 1,5,8 stay live)
+    V in[9], G[9], mac[3];
     if (!BODY || ia + g.gi0 > 0) {        // column ia-1 exists (ia = 0 on the inlet side: its step 2 is the far field)
         march_load_stream(a, ia - 1, in);
         STEP1(ia - 1, in, G);
         G158m[0] = G[1]; G158m[1] = G[5]; G158m[2] = G[8];
     } else {
-        G158m[0] = v4_splat(feq0[1]); G158m[1] = v4_splat(feq0[5]); G158m[2] = v4_splat(feq0[8]);
+        G158m[0] = mv_splat<T, S>(feq0[1]); G158m[1] = mv_splat<T, S>(feq0[5]); G158m[2] = mv_splat<T, S>(feq0[8]);
     }
     march_load_stream(a, ia, in);
     STEP1(ia, in, Gc);
     march_load_stream(a, ia + 1, in);
-    unsigned hv = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (unsigned)ia * 32u, 0);
+    T hv = halo_load<T>(rh, hoff, (unsigned)ia * HREC);
     int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
 #pragma unroll 1
     for (int c = ia; c < ib; c++) {
-        V4 nxt[9];
+        V nxt[9];
         march_load_stream(a, (c + 2 <= ib) ? c + 2 : c + 1, nxt);             // prefetch (last one: harmless re-load)
-        const unsigned hv_next = __builtin_amdgcn_raw_buffer_load_b32(rh, hoff, (unsigned)(c + 1) * 32u, 0);
-        const SeamPair sp = seam_fetch(a);                                    // staged by the previous iteration's march_store
+        const T hv_next = halo_load<T>(rh, hoff, (unsigned)(c + 1) * HREC);
+        const SeamPair<T> sp = seam_fetch(a);                                 // staged by the previous iteration's march_store
         STEP1(c + 1, in, G);                                                  // step 1 of column c+1
-        const float hb2 = __uint_as_float(__builtin_amdgcn_readlane(hv, 0)), hb5 = __uint_as_float(__builtin_amdgcn_readlane(hv, 1)),
-                    hb6 = __uint_as_float(__builtin_amdgcn_readlane(hv, 2)), ha4 = __uint_as_float(__builtin_amdgcn_readlane(hv, 3)),
-                    ha7 = __uint_as_float(__builtin_amdgcn_readlane(hv, 4)), ha8 = __uint_as_float(__builtin_amdgcn_readlane(hv, 5));
+        const T hb2 = readlane_t(hv, 0), hb5 = readlane_t(hv, 1), hb6 = readlane_t(hv, 2), ha4 = readlane_t(hv, 3), ha7 = readlane_t(hv, 4),
+                ha8 = readlane_t(hv, 5);
         // ---- step 2 of column c
-        V4 fin[9], out[9];
+        V fin[9], out[9];
         fin[0] = Gc[0]; fin[1] = G158m[0]; fin[3] = G[3];
         fin[2] = m_below(Gc[2], lane, hb2); fin[5] = m_below(G158m[1], lane, hb5); fin[6] = m_below(G[6], lane, hb6);
         fin[4] = m_above(Gc[4], lane, ha4); fin[8] = m_above(G158m[2], lane, ha8); fin[7] = m_above(G[7], lane, ha7);
@@ -615,28 +725,28 @@ __device__ __forceinline__ void march_unit(const MarchParams &p, MarchAddr &a, _
                 auto ownc = [&](int k) { return Gc[k]; };
                 uint32_t solid4 = 0, code4 = 0;
                 if (nf) {
-                    solid4 = *reinterpret_cast<const uint32_t *>(p.mask + (long)(c + 1) * g.pitch + j0);
-                    code4 = *reinterpret_cast<const uint32_t *>(p.bcode + (long)c * g.pitch + j0);
+                    solid4 = load_site_bytes<S>(p.mask + (long)(c + 1) * g.pitch + j0);
+                    code4 = load_site_bytes<S>(p.bcode + (long)c * g.pitch + j0);
                 }
                 const bool any_solid = __ballot(solid4 != 0) != 0ULL;
                 if (gi <= 0) {
 #pragma unroll
-                    for (int k = 0; k < 9; k++) out[k] = v4_splat(feq0[k]);
-                    if (EMIT) { mac[0] = v4_splat(1.0f); mac[1] = v4_splat(p.U0); mac[2] = v4_splat(0.0f); }
+                    for (int k = 0; k < 9; k++) out[k] = mv_splat<T, S>(feq0[k]);
+                    if (EMIT) { mac[0] = mv_splat<T, S>(T(1)); mac[1] = mv_splat<T, S>(p.U0); mac[2] = mv_splat<T, S>(T(0)); }
                 } else if (ALLSOLID(c)) {
 #pragma unroll
                     for (int k = 0; k < 9; k++) out[k] = Gc[k];        // every site is overwritten by march_solid below
-                    if (EMIT) { mac[0] = v4_splat(1.0f); mac[1] = v4_splat(0.0f); mac[2] = v4_splat(0.0f); }
+                    if (EMIT) { mac[0] = mv_splat<T, S>(T(1)); mac[1] = mv_splat<T, S>(T(0)); mac[2] = mv_splat<T, S>(T(0)); }
                 } else {
-                    march_bounce(fin, code4, ownc);
-                    march_collide_general<FD, EMIT>(fin, solid4, j0, g.ny, p.fdv, p.U0, feq0, out, mac);
+                    march_bounce<T, S>(fin, code4, ownc);
+                    march_collide_general<T, S, FD, EMIT>(fin, solid4, j0, g.ny, p.fdv, p.tau, p.U0, feq0, out, mac);
                 }
-                if (any_solid && (gi <= 0 || ALLSOLID(c))) march_solid<EMIT>(out, mac, solid4, ownc);
+                if (any_solid && (gi <= 0 || ALLSOLID(c))) march_solid<T, S, EMIT>(out, mac, solid4, ownc);
             }
         }
         if (plain) {
-            march_collide<FD, EMIT>(fin, p.fdv, out, mac);
-            if (far_win) march_far_rows<EMIT>(j0, g.ny, p.U0, feq0, out, mac);
+            march_collide<T, S, FD, EMIT>(fin, p.fdv, p.tau, out, mac);
+            if (far_win) march_far_rows<T, S, EMIT>(j0, g.ny, p.U0, feq0, out, mac);
         }
         march_store<EMIT>(a, c, out, mac);
         seam_flush(a, seam_col, sp);
@@ -645,12 +755,12 @@ __device__ __forceinline__ void march_unit(const MarchParams &p, MarchAddr &a, _
             // outlet column NX-1 (html:301-312): its step-2 value is the step-1 state of column NX-2 (= Gc), its own
             // step-1 state (solid sites only) is G
             uint32_t solid4 = 0;
-            if (NONFAST(c + 1)) solid4 = *reinterpret_cast<const uint32_t *>(p.mask + (long)(c + 2) * g.pitch + j0);
+            if (NONFAST(c + 1)) solid4 = load_site_bytes<S>(p.mask + (long)(c + 2) * g.pitch + j0);
             auto ownp = [&](int k) { return G[k]; };
 #pragma unroll
             for (int k = 0; k < 9; k++) out[k] = Gc[k];
             if (EMIT) march_outlet_macro(Gc, mac);
-            if (__ballot(solid4 != 0) != 0ULL) march_solid<EMIT>(out, mac, solid4, ownp);
+            if (__ballot(solid4 != 0) != 0ULL) march_solid<T, S, EMIT>(out, mac, solid4, ownp);
             seam_flush(a, seam_col, seam_fetch(a));          // column c's seam rows, before the staging area is reused
             march_store<EMIT>(a, c + 1, out, mac);
             seam_col = c + 1;
@@ -666,9 +776,11 @@ __device__ __forceinline__ void march_unit(const MarchParams &p, MarchAddr &a, _
 #undef STEP1
 }
 
-template <bool EMIT, int FD>
-__global__ __launch_bounds__(256, 2) void k_march(MarchParams p)
+template <typename T, int S, bool EMIT, int FD>
+__global__ __launch_bounds__(256, 2) void k_march(MarchParams<T> p)
 {
+    constexpr int WIN = 64 * S;
+    constexpr unsigned EB = sizeof(T);
     const Geom &g = p.g;
     const int lane = threadIdx.x & 63;
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -678,46 +790,46 @@ __global__ __launch_bounds__(256, 2) void k_march(MarchParams p)
     const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
     const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
     if (ib <= ia) return;                                          // padding unit (keeps the block -> XCD pattern of the list)
-    const int row0 = w * MARCH_WIN;
-    const int j0 = row0 + lane * 4;
-    const bool far_win = (w == 0) || (row0 + MARCH_WIN >= g.ny);   // the window holds row 0 or row NY-1
-    MarchAddr a;
+    const int row0 = w * WIN;
+    const int j0 = row0 + lane * S;
+    const bool far_win = (w == 0) || (row0 + WIN >= g.ny);         // the window holds row 0 or row NY-1
+    MarchAddr<T, S> a;
     a.rs = march_rsrc(p.fs, p.lat_bytes);
     a.rd = march_rsrc(p.fd, p.lat_bytes);
-    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
-    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * 4u;          // lanes beyond the last row re-read the window's first rows (cached) and store nothing
-    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * 4u : p.lat_bytes;   // >= num_records of both the lattice and the macro buffer
-    a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
+    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * EB));
+    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * EB;           // lanes beyond the last row re-read the window's first rows (cached) and store nothing
+    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * EB : p.lat_bytes;    // >= num_records of both the lattice and the macro buffer
+    a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
     // halo table: lanes 0..5 fetch, for step 2 of column c, {G2(c), G5(c-1), G6(c+1)} of the row below the window
-    // (seam w) and {G4(c), G7(c+1), G8(c-1)} of the row above it (seam w+1); record = 8 floats per (seam, column)
-    const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.halo, (unsigned)((unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 32u));
+    // (seam w) and {G4(c), G7(c+1), G8(c-1)} of the row above it (seam w+1); record = 8 elements per (seam, column)
+    const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.halo, (unsigned)((unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 8u * EB));
     unsigned hoff;
     {
         const int hl = lane < 6 ? lane : 0;
         const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
         const int slot = hl < 3 ? hl : hl + 1;
         const int seam = hl < 3 ? w : w + 1;
-        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 32 + slot * 4);
+        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 8 + slot) * EB;
     }
     {
-        // S record of (seam b, column x) = 192 bytes: half 0 = rows 256b-2, 256b-1 (written by window b-1), half 1 = rows
-        // 256b, 256b+1 (written by window b); a half = 12 slots of 2 floats, slot k < 9 = direction k
+        // S record of (seam b, column x) = 48 elements: half 0 = rows WIN*b-2, WIN*b-1 (written by window b-1), half 1 = rows
+        // WIN*b, WIN*b+1 (written by window b); a half = 12 slots of 2 elements, slot k < 9 = direction k
         // per wave: below[24] (lane 63 stages pairs 0..8, slots 9..11 stay zero), above[24] (lane 0), then a scratch area
         // the other 62 lanes stage into (an LDS write per lane is cheaper than a branch around two-lane writes)
-        __shared__ float seam_lds[4][48 + 160];
-        float *wl = &seam_lds[threadIdx.x >> 6][0];
+        __shared__ T seam_lds[4][48 + 160];
+        T *wl = &seam_lds[threadIdx.x >> 6][0];
         a.lane = lane;
         a.lds_w = lane == 63 ? wl : (lane == 0 ? wl + 24 : wl + 48 + 2 * lane);
         a.lds_r = wl + 2 * (lane < 12 ? lane : 0);
-        if (lane < 48) wl[lane] = 0.0f;
-        const unsigned sbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 192u;
+        if (lane < 48) wl[lane] = T(0);
+        const unsigned sbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 48u * EB;
         a.rseam = march_rsrc(p.seams, sbytes);
-        const unsigned rec = (unsigned)(g.nxl + 2) * 192u;
-        a.voff_lo = lane < 12 ? (unsigned)w * rec + 96u + (unsigned)lane * 8u : sbytes;
-        a.voff_hi = lane < 12 ? (unsigned)(w + 1) * rec + (unsigned)lane * 8u : sbytes;
+        const unsigned rec = (unsigned)(g.nxl + 2) * 48u * EB;
+        a.voff_lo = lane < 12 ? (unsigned)w * rec + 24u * EB + (unsigned)lane * 2u * EB : sbytes;
+        a.voff_hi = lane < 12 ? (unsigned)(w + 1) * rec + (unsigned)lane * 2u * EB : sbytes;
     }
-    float feq0[9];
-    feq_all<float>(1.0f, p.U0, 0.0f, feq0);                       // far-field populations (html:314-322)
+    T feq0[9];
+    feq_all<T>(T(1), p.U0, T(0), feq0);                           // far-field populations (html:314-322)
 
     // classes of columns ia-1 .. ib (lane l <-> column ia-1+l): two 64-bit scalars
     unsigned long long nonfast_m, solid_m;
@@ -730,8 +842,8 @@ __global__ __launch_bounds__(256, 2) void k_march(MarchParams p)
     }
     // a unit whose whole footprint (columns ia-1 .. ib) is plain interior fluid takes the lean loop
     const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= 2 && ib + g.gi0 <= g.nx_g - 2 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
-    if (lean) march_unit<false, EMIT, FD>(p, a, rh, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
-    else march_unit<true, EMIT, FD>(p, a, rh, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+    if (lean) march_unit<false, EMIT, FD, T, S>(p, a, rh, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+    else march_unit<true, EMIT, FD, T, S>(p, a, rh, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -762,10 +874,10 @@ struct MarchPlan {
 // COST — a FAST column costs 1, any other column 1 + alpha (its step 1 waits for nine more loads) — such that
 // the total is at most `target_units` (a multiple of `slots` chosen by the caller), or, when max_cost > 0, into
 // units of at most max_cost (tests, experiments).
-static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, long target_units, int max_cost = 0, double alpha = 1.0)
+static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int win, long target_units, int max_cost = 0, double alpha = 1.0)
 {
     MarchPlan pl;
-    const int nwin = march_nwin(g.ny), ld = g.nxl + 2;
+    const int nwin = march_nwin(g.ny, win), ld = g.nxl + 2;
     pl.nwin = nwin;
     const MarchRange r = march_range(g);
     const int ncol = r.i_end - r.i_begin;

@@ -91,16 +91,19 @@ struct wt_handle {
     int transport = TR_NONE;
     ncclComm_t comm = nullptr;
     wt_handle *peer_l = nullptr, *peer_r = nullptr;   // TR_LOCAL
-    // two-steps-per-launch mode (step_march.hpp); fp32 handles with NY % 4 == 0
+    // two-steps-per-launch mode (step_march.hpp)
     bool fuse = false;
+    int fuse_sites = 0;                  // option: sites per lane of the marching kernel (0 = automatic; 2 or 4)
+    long long march_table_bytes = 0;     // wcls + halo_tab + seams + seam_plain (part of device_bytes)
+    int march_s = 0;                     // sites per lane in use (4: fp32 256-row windows; 2: fp64, or fp32 on narrow lattices)
     bool fuse_force = false;             // fuse_steps = 2: also when the lattice is too small for it to pay
     int fuse_chunk = 0;                  // cost limit of a unit (columns); 0 = whole resident rounds of units (build_march_plan)
     bool fuse_ready = false;
     int fuse_chunk_used = 0;
     uint8_t *bcode = nullptr;            // bounce codes, (nxl+2) * pitch
     uint8_t *wcls = nullptr;             // window-tile classes, nwin * (nxl+2)
-    float *halo_tab = nullptr;           // halo table of the marching kernels, (nwin+1) * (nxl+2) * 8
-    float *seams = nullptr;              // seam rows written by a marching pass beside its output lattice, (nwin+1) * (nxl+2) * 48
+    void *halo_tab = nullptr;            // halo table of the marching kernels, (nwin+1) * (nxl+2) * 8 elements
+    void *seams = nullptr;               // seam rows written by a marching pass beside its output lattice, (nwin+1) * (nxl+2) * 48 elements
     uint8_t *seam_plain = nullptr;       // per (seam, column): both sites next to the seam are plain interior fluid, (nwin-1) * nxl
     bool seams_valid = false;            // `seams` describes lattice f[cur] (set by a marching pass, cleared by everything else that writes f)
     MarchUnit *d_units = nullptr;
@@ -306,43 +309,54 @@ extern "C" int wt_sync(wt_handle *h)
 // ------------------------------------------------------------------------------------------
 // whole lattices and column slabs alike (a slab plans over its LOCAL columns, ghosts included); the
 // marching kernels address a lattice through one 32-bit buffer descriptor
-static bool fuse_eligible(const wt_handle *h)
+static bool fuse_eligible_s(const wt_handle *h, int sites)
 {
-    return h->dtype == WT_F32 && h->g.ny % 4 == 0 && h->g.nxl >= 8 && (unsigned long long)9 * h->g.plane * 4ULL < (1ULL << 32) - (1ULL << 20);
+    const unsigned long long eb = h->dtype == WT_F32 ? 4 : 8;
+    if (sites * eb != 16 && !(h->dtype == WT_F32 && sites == 2)) return false;
+    return h->g.ny % sites == 0 && h->g.nxl >= 8 && 9ULL * h->g.plane * eb < (1ULL << 32) - (1ULL << 20);
+}
+static bool fuse_eligible(const wt_handle *h) { return fuse_eligible_s(h, 2) || fuse_eligible_s(h, 4); }
+
+static void free_march_tables(wt_handle *h)
+{
+    if (h->wcls) { (void)hipFree(h->wcls); h->wcls = nullptr; }
+    if (h->halo_tab) { (void)hipFree(h->halo_tab); h->halo_tab = nullptr; }
+    if (h->seams) { (void)hipFree(h->seams); h->seams = nullptr; }
+    if (h->seam_plain) { (void)hipFree(h->seam_plain); h->seam_plain = nullptr; }
+    h->seams_valid = false;
+    h->n_win = 0;
+    h->device_bytes -= h->march_table_bytes;
+    h->march_table_bytes = 0;
 }
 
-// Classes, bounce codes and the unit lists of the current mask.  Everything but the two cuts of the
-// column ranges runs on the device; the host reads nwin x (nxl+2) class bytes back.
-static int rebuild_fuse_plan(wt_handle *h)
+// Classes, bounce codes and the unit lists of the current mask for windows of 64 * sites rows.  Everything but the
+// cuts of the column ranges runs on the device; the host reads nwin x (nxl+2) class bytes back.
+static int build_fuse_plan(wt_handle *h, int sites, long target)
 {
-    h->fuse_ready = false;
-    h->n_units = h->nonfast_tiles = 0;
-    if (!h->fuse || !fuse_eligible(h) || !h->mask_set) return WT_OK;
     const Geom &g = h->g;
-    const int nwin = march_nwin(g.ny);
+    const int win = 64 * sites;
+    const size_t eb = h->dtype == WT_F32 ? 4 : 8;
+    const int nwin = march_nwin(g.ny, win);
     const size_t wbytes = (size_t)nwin * (g.nxl + 2), cbytes = (size_t)(g.nxl + 2) * g.pitch;
-    if (!h->wcls || h->n_win != nwin) {
-        if (h->wcls) { HIP_TRY(hipFree(h->wcls)); h->wcls = nullptr; }
-        HIP_TRY(hipMalloc((void **)&h->wcls, wbytes));
-        h->device_bytes += (long long)wbytes;
-    }
+    if (h->n_win != nwin || h->march_s != sites) free_march_tables(h);
+    long long added = 0;
+    if (!h->wcls) { HIP_TRY(hipMalloc((void **)&h->wcls, wbytes)); added += (long long)wbytes; }
     if (!h->halo_tab) {
-        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * sizeof(float);
-        HIP_TRY(hipMalloc((void **)&h->halo_tab, hbytes));
+        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb;
+        HIP_TRY(hipMalloc(&h->halo_tab, hbytes));
         HIP_TRY(hipMemsetAsync(h->halo_tab, 0, hbytes, h->s_compute));
-        h->device_bytes += (long long)hbytes;
+        added += (long long)hbytes;
     }
     if (!h->seams) {
-        const size_t sbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 48 * sizeof(float);
-        HIP_TRY(hipMalloc((void **)&h->seams, sbytes));
+        const size_t sbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 48 * eb;
+        HIP_TRY(hipMalloc(&h->seams, sbytes));
         HIP_TRY(hipMemsetAsync(h->seams, 0, sbytes, h->s_compute));
-        h->device_bytes += (long long)sbytes;
         h->seams_valid = false;
+        added += (long long)sbytes;
     }
-    if (!h->seam_plain && nwin > 1) {
-        HIP_TRY(hipMalloc((void **)&h->seam_plain, (size_t)(nwin - 1) * g.nxl));
-        h->device_bytes += (long long)(nwin - 1) * g.nxl;
-    }
+    if (!h->seam_plain && nwin > 1) { HIP_TRY(hipMalloc((void **)&h->seam_plain, (size_t)(nwin - 1) * g.nxl)); added += (long long)(nwin - 1) * g.nxl; }
+    h->march_table_bytes += added;
+    h->device_bytes += added;
     if (!h->bcode) {
         HIP_TRY(hipMalloc((void **)&h->bcode, cbytes));
         HIP_TRY(hipMemsetAsync(h->bcode, 0, cbytes, h->s_compute));
@@ -350,32 +364,22 @@ static int rebuild_fuse_plan(wt_handle *h)
     }
     if (!h->d_nbad) HIP_TRY(hipMalloc((void **)&h->d_nbad, sizeof(unsigned int)));
     h->n_win = nwin;
+    h->march_s = sites;
     const long nt = (long)(g.nxl + 2) * nwin;
-    hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->wcls, g, nwin);
+    hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->wcls, g, nwin, win);
     hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->bcode, g);
     if (nwin > 1) {
         const long nth = (long)(nwin - 1) * g.nxl;
         hipLaunchKernelGGL(k_seam_flags, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
-                           h->seam_plain, g, nwin);
+                           h->seam_plain, g, nwin, win);
     }
     HIP_TRY(hipGetLastError());
     h->host_wcls.resize(wbytes);
     HIP_TRY(hipMemcpyAsync(h->host_wcls.data(), h->wcls, wbytes, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
 
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-    const long slots = (long)prop.multiProcessorCount * 4 * 2;           // two resident marching waves per SIMD
     const MarchRange r = march_range(g);
-    const long tiles = (long)(r.i_end - r.i_begin) * nwin;
-    // Whole resident rounds of units (see build_march_plan): two rounds where that leaves at least 12 columns per
-    // unit (4096^2: 4096 units of 16 columns; the two re-read halo columns of a unit are then 12 % of its loads), else
-    // one.  Measured (bench.py --nx 544/1056/2080 --fuse 2): with fewer than one round of 6-column units the marching
-    // kernel cannot fill the chip and the single-step kernel is faster.
-    long target = 2 * slots;
-    if (tiles / target < 12) target = slots;
-    if (!h->fuse_force && h->fuse_chunk <= 0 && tiles / target < 6) return WT_OK;
-    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, target, h->fuse_chunk, 2.0);
+    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, 2.0);
     const size_t total = pl.units.size();
     if (total == 0) return WT_OK;
     if (total > h->units_cap) {
@@ -390,7 +394,51 @@ static int rebuild_fuse_plan(wt_handle *h)
     h->fuse_chunk_used = pl.chunk;
     for (int w = 0; w < nwin; w++)
         for (int x = r.i_begin; x < r.i_end; x++) h->nonfast_tiles += h->host_wcls[(size_t)w * (g.nxl + 2) + x + 1] != WC_FAST;
-    h->fuse_ready = true;
+    return WT_OK;
+}
+
+// Whole resident rounds of units (see build_march_plan): two rounds where that leaves at least 12 columns per unit
+// (4096^2: 4096 units of 16 columns; the two re-read halo columns of a unit are then 12 % of its loads), else one.
+// Returns 0 when the plan would not pay: with fewer than one round of min_cols-column units the two redundant step-1
+// columns of every unit outweigh the saved traffic (measured with 2 sites per lane on 4096 rows: 288 columns = 4.5 per
+// unit 18.7 us/step against 21.2 for single steps; 544 columns 25.1 against 33.5).
+static long march_target_units(const wt_handle *h, int sites, long slots, bool force, int min_cols)
+{
+    const MarchRange r = march_range(h->g);
+    const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * sites);
+    if (!force && h->fuse_chunk <= 0 && tiles / slots < min_cols) return 0;      // columns per unit in ONE round
+    long target = 2 * slots;
+    if (tiles / target < 12) target = slots;
+    return target;
+}
+
+// Sites per lane: fp64 always 2 (16-byte vectors); fp32 4 (256-row windows) where that plan has enough units to pay,
+// else 2 (128-row windows: twice the units — narrow lattices such as column slabs); option fuse_sites overrides.
+// The choice depends on the geometry only, so a mask change rebuilds the tables in place.
+static int rebuild_fuse_plan(wt_handle *h)
+{
+    h->fuse_ready = false;
+    h->n_units = h->nonfast_tiles = 0;
+    if (!h->fuse || !fuse_eligible(h) || !h->mask_set) return WT_OK;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    long waves = 2;                                                      // resident marching waves per SIMD
+    if (const char *e = getenv("WT_MARCH_WAVES")) waves = atoi(e) > 0 ? atoi(e) : 2;
+    const long slots = (long)prop.multiProcessorCount * 4 * waves;
+    int order[2] = {4, 2}, n = 2;
+    if (h->dtype != WT_F32) { order[0] = 2; n = 1; }
+    else if (h->fuse_sites == 2 || h->fuse_sites == 4) { order[0] = h->fuse_sites; n = 1; }
+    for (int t = 0; t < n; t++) {
+        if (!fuse_eligible_s(h, order[t])) continue;
+        // automatic choice on fp32: 256-row windows only where one round of them gets 16 columns per unit (measured on
+        // 4096 rows: 2080 columns 81.0 us/step with 4 sites vs 82.5 with 2; 1056 columns 48.0 vs 43.5; 544 columns 31.1 vs
+        // 25.9 against 33.5 for single steps)
+        const long target = march_target_units(h, order[t], slots, h->fuse_force && t == n - 1, (n == 2 && t == 0) ? 16 : 4);
+        if (target == 0) continue;
+        WT_TRY(build_fuse_plan(h, order[t], target));
+        h->fuse_ready = h->n_units > 0;
+        break;
+    }
     return WT_OK;
 }
 
@@ -401,9 +449,16 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
     HIP_TRY(hipSetDevice(h->device));
     if (strcmp(name, "fuse_steps") == 0) {
         if (value != 0.0 && !fuse_eligible(h))
-            return fail(WT_ERR_STATE, "fuse_steps needs an fp32 handle with NY %% 4 == 0, at least 8 local columns and a lattice below 4 GiB");
+            return fail(WT_ERR_STATE, "fuse_steps needs an even NY, at least 8 local columns and a lattice below 4 GiB");
         h->fuse = value != 0.0;
         h->fuse_force = value >= 2.0;
+        return rebuild_fuse_plan(h);
+    }
+    if (strcmp(name, "fuse_sites") == 0) {
+        if (!(value == 0.0 || value == 2.0 || value == 4.0)) return fail(WT_ERR_ARG, "fuse_sites must be 0 (automatic), 2 or 4");
+        if (value != 0.0 && !fuse_eligible_s(h, (int)value))
+            return fail(WT_ERR_STATE, "fuse_sites: this handle cannot march with that many sites per lane (fp64: 2; NY must be a multiple of it)");
+        h->fuse_sites = (int)value;
         return rebuild_fuse_plan(h);
     }
     if (strcmp(name, "fuse_chunk") == 0) {
@@ -426,6 +481,7 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "fuse_active") == 0) { *value = h->fuse_ready ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_ready ? h->fuse_chunk_used : h->fuse_chunk; return WT_OK; }
     if (strcmp(name, "fuse_units") == 0) { *value = h->n_units; return WT_OK; }
+    if (strcmp(name, "fuse_sites") == 0) { *value = h->fuse_ready ? h->march_s : h->fuse_sites; return WT_OK; }
     if (strcmp(name, "fuse_tiles_general") == 0) { *value = h->nonfast_tiles; return WT_OK; }   // window-tiles that take the body paths
     if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
@@ -668,57 +724,60 @@ static int fastdiv_for(wt_handle *h, float tau, bool *use)
     return WT_OK;
 }
 
-template <bool EMIT, int FD>
-static void launch_march(const MarchParams &p, hipStream_t st)
+template <typename T, int S, bool EMIT, int FD>
+static void launch_march(const MarchParams<T> &p, hipStream_t st)
 {
     if (p.nunits <= 0) return;
-    hipLaunchKernelGGL((k_march<EMIT, FD>), dim3((unsigned)((p.nunits + 3) / 4)), dim3(256), 0, st, p);
-}
-
-static void launch_march_any(const MarchParams &p, bool emit, bool fd, hipStream_t st)
-{
-    if (emit) { if (fd) launch_march<true, 1>(p, st); else launch_march<true, 0>(p, st); }
-    else { if (fd) launch_march<false, 1>(p, st); else launch_march<false, 0>(p, st); }
+    hipLaunchKernelGGL((k_march<T, S, EMIT, FD>), dim3((unsigned)((p.nunits + 3) / 4)), dim3(256), 0, st, p);
 }
 
 // Two steps in one pass over the lattice (step_march.hpp).  A = f[cur] (time t), B = f[1-cur] (receives time t+2).
-static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
+template <typename T, int S, int FD>
+static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
 {
     const Geom &g = h->g;
-    bool fd = false;
-    WT_TRY(fastdiv_for(h, (float)tau, &fd));
-    MarchParams p;
-    p.fs = fptr<float>(h, h->cur);
-    p.fd = fptr<float>(h, 1 - h->cur);
-    p.macro = reinterpret_cast<float *>(h->macro);
-    p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls; p.halo = h->halo_tab; p.seams = h->seams;
+    MarchParams<T> p;
+    p.fs = fptr<T>(h, h->cur);
+    p.fd = fptr<T>(h, 1 - h->cur);
+    p.macro = reinterpret_cast<T *>(h->macro);
+    p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls;
+    p.halo = reinterpret_cast<const T *>(h->halo_tab); p.seams = reinterpret_cast<T *>(h->seams);
     p.g = g;
-    p.lat_bytes = (unsigned)((size_t)9 * g.plane * 4);
+    p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(T));
     p.nwin_total = h->n_win;
     p.fdv.tau = (float)tau; p.fdv.rtau = 1.0f / (float)tau;
-    p.U0 = (float)u0;
+    p.tau = (T)tau;
+    p.U0 = (T)u0;
     p.rev = (int)((h->steps_done >> 1) & 1);
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // the step-1 populations that cross the window seams
         const long nth = (long)(h->n_win - 1) * g.nxl;
         const dim3 grid((unsigned)((nth + 255) / 256)), block(256);
-        const uint8_t *mk = h->mask, *bc = h->seam_plain;
-        if (h->seams_valid) {   // the previous pass left the seam rows of this lattice in `seams`: coalesced loads
-            if (fd) hipLaunchKernelGGL((k_halo_from_seams<1>), grid, block, 0, st, p.fs, (const float *)h->seams, mk, bc, h->halo_tab, g, h->n_win, p.fdv, p.U0);
-            else hipLaunchKernelGGL((k_halo_from_seams<0>), grid, block, 0, st, p.fs, (const float *)h->seams, mk, bc, h->halo_tab, g, h->n_win, p.fdv, p.U0);
-        } else {                // gather from the lattice (first pass after a single step, an upload, a ghost refresh)
-            if (fd) hipLaunchKernelGGL((k_halo_rows<1>), grid, block, 0, st, p.fs, mk, bc, h->halo_tab, g, h->n_win, p.fdv, p.U0);
-            else hipLaunchKernelGGL((k_halo_rows<0>), grid, block, 0, st, p.fs, mk, bc, h->halo_tab, g, h->n_win, p.fdv, p.U0);
-        }
+        const uint8_t *mk = h->mask, *sp = h->seam_plain;
+        T *ht = reinterpret_cast<T *>(h->halo_tab);
+        if (h->seams_valid)     // the previous pass left the seam rows of this lattice in `seams`: coalesced loads
+            hipLaunchKernelGGL((k_halo_from_seams<T, FD>), grid, block, 0, st, p.fs, (const T *)p.seams, mk, sp, ht, g, h->n_win, 64 * S, p.fdv, p.tau, p.U0);
+        else                    // gather from the lattice (first pass after a single step, an upload, a ghost refresh)
+            hipLaunchKernelGGL((k_halo_rows<T, FD>), grid, block, 0, st, p.fs, mk, sp, ht, g, h->n_win, 64 * S, p.fdv, p.tau, p.U0);
     }
     p.units = h->d_units; p.nunits = h->n_units;
-    launch_march_any(p, emit, fd, st);
+    if (emit) launch_march<T, S, true, FD>(p, st);
+    else launch_march<T, S, false, FD>(p, st);
     HIP_TRY(hipGetLastError());
     h->cur = 1 - h->cur;
     h->steps_done += 2;
     h->seams_valid = true;                       // the pass wrote the seam rows of the lattice it produced
     if (h->nranks > 1) h->ghost_valid -= 2;      // two columns of ghost validity consumed
     return WT_OK;
+}
+
+static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
+{
+    if (h->dtype != WT_F32) return step_pair_fused_t<double, 2, 0>(h, tau, u0, emit);
+    bool fd = false;
+    WT_TRY(fastdiv_for(h, (float)tau, &fd));
+    if (h->march_s == 4) return fd ? step_pair_fused_t<float, 4, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 4, 0>(h, tau, u0, emit);
+    return fd ? step_pair_fused_t<float, 2, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 2, 0>(h, tau, u0, emit);
 }
 
 // a fused pair is possible now: plan ready and (slabs) two exact ghost columns left

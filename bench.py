@@ -67,6 +67,7 @@ def parse_args():
                     help="two steps per pass over the lattice (csrc/step_march.hpp; fp32; bit-identical): -1 library "
                          "default (on where it pays), 0 off, 1 where it pays, 2 always")
     ap.add_argument("--fuse-chunk", type=int, default=0, help="cost limit of a marching unit in columns (0 = whole resident rounds)")
+    ap.add_argument("--fuse-sites", type=int, default=0, choices=[0, 2, 4], help="sites per lane of the marching kernel (0 = automatic)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -217,11 +218,12 @@ def main():
             eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank, rank=rank, nranks=world, halo=args.halo)
         else:
             eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank)
-        if args.dtype == "float32":
-            if args.fuse_chunk > 0:
-                eng.set_option("fuse_chunk", args.fuse_chunk)
-            if args.fuse >= 0:
-                eng.set_option("fuse_steps", args.fuse)
+        if args.fuse_chunk > 0:
+            eng.set_option("fuse_chunk", args.fuse_chunk)
+        if args.fuse_sites > 0:
+            eng.set_option("fuse_sites", args.fuse_sites)
+        if args.fuse >= 0:
+            eng.set_option("fuse_steps", args.fuse)
         if distributed:
             # 2. the library's own communicator (beside torch's): unique id through torch.distributed, join under a watchdog
             ids = [wtpkg.Engine.comm_unique_id() if rank == 0 else None]
@@ -272,7 +274,7 @@ def main():
     launch_ms = dev_ms / args.steps * steps_per_launch     # one launch = one pass of the dominant kernel over the slab
     sites_per_launch = eng.width * ny if not distributed else (nx_total // world) * ny
     key = f"{nx_total}x{ny}_{args.dtype}"
-    main_kernel = ("wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_rows per pass)" if fused else "wt::k_step")
+    main_kernel = ("wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)" if fused else "wt::k_step")
     traffic = None if distributed else measured_traffic(key + ("_march" if fused else ""))
     r = roofline_entry(main_kernel, bpl * sites_per_launch * steps_per_launch, launch_ms, traffic)
     # `achieved` is the REAL HBM rate (counters) when this workload has been profiled, else the effective rate
@@ -280,6 +282,7 @@ def main():
     achieved = r["counter_gbps"] if r["counter_gbps"] is not None else r["effective_gbps"]
     cfg_fuse = {"fuse_steps": int(fused), "fuse_chunk": int(eng.get_option("fuse_chunk")) if fused else 0,
                 "fuse_units": int(eng.get_option("fuse_units")) if fused else 0,
+                "fuse_sites": int(eng.get_option("fuse_sites")) if fused else 0,
                 "fast_div": int(eng.get_option("fast_div_active")) if fused else 0}
     roofline = {"bound": "hbm", "kernel": main_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,

@@ -1,7 +1,9 @@
 """GPU: the two-steps-per-launch mode (csrc/step_march.hpp) must be bit-identical to the ordinary
 single-step path and to the oracle: plain units (register-resident step 1 -> step 2), body units
 (window-tile classes, bounce codes, inlet / outlet columns inside the march), odd/even step counts,
-macro emission, mask changes, chunk sizes, the proved fast division by tau and its IEEE fallback."""
+macro emission, mask changes, chunk sizes, the proved fast division by tau and its IEEE fallback; all three
+instantiations — fp32 with 4 sites per lane (256-row windows), fp32 with 2 (128-row windows, narrow lattices) and
+fp64 with 2."""
 import numpy as np
 import pytest
 
@@ -10,17 +12,22 @@ from conftest import bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None):
+def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None, sites=0, dtype="float32"):
     ny, nx = mask.shape
-    with pkg.Engine(nx, ny) as e:
+    with pkg.Engine(nx, ny, dtype=dtype) as e:
+        e.set_option("fuse_steps", 0)
         if fuse:
             if chunk is not None:
                 e.set_option("fuse_chunk", chunk)
+            if sites:
+                e.set_option("fuse_sites", sites)
             e.set_option("fuse_steps", 2)
         e.set_mask(mask)
         e.init_equilibrium(u0)
         if fuse:
             assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_units") > 0
+            if sites:
+                assert e.get_option("fuse_sites") == sites
         for n in chunks:
             e.step(n, tau, u0)
         return e.read_f(), e.read_macro(), e.info().steps_done
@@ -43,11 +50,12 @@ def _body(pkg, nx, ny, shape="naca2412", aoa=7.0):
 ])
 def test_fused_equals_single_step(pkg, nx, ny, chunks, chunk):
     mask = _body(pkg, nx, ny)
-    f0, m0, n0 = _run(pkg, mask, chunks, 0.58, 0.06, False)
-    f1, m1, n1 = _run(pkg, mask, chunks, 0.58, 0.06, True, chunk)
-    assert n0 == n1 == sum(chunks)
-    assert bits_equal(f0, f1)
-    assert all(bits_equal(a, b) for a, b in zip(m0, m1))
+    for dtype, sites in (("float32", 4), ("float32", 2), ("float64", 2)):
+        f0, m0, n0 = _run(pkg, mask, chunks, 0.58, 0.06, False, dtype=dtype)
+        f1, m1, n1 = _run(pkg, mask, chunks, 0.58, 0.06, True, chunk, sites, dtype)
+        assert n0 == n1 == sum(chunks)
+        assert bits_equal(f0, f1), (dtype, sites)
+        assert all(bits_equal(a, b) for a, b in zip(m0, m1)), (dtype, sites)
 
 
 def test_fused_vs_oracle_and_edge_masks(pkg, oracle_c):
@@ -56,24 +64,36 @@ def test_fused_vs_oracle_and_edge_masks(pkg, oracle_c):
     wall = np.zeros((ny, nx), np.uint8); wall[:, 200:204] = 1
     specks = np.zeros((ny, nx), np.uint8); specks[::37, ::53] = 1; specks[255:257, 100:110] = 1; specks[251:254, 300] = 1
     edges = np.zeros((ny, nx), np.uint8); edges[0, 10:20] = 1; edges[ny - 1, 30:40] = 1; edges[50:60, 0] = 1; edges[70:90, nx - 1] = 1; edges[100:140, 2] = 1
+    specks[127:129, 400:410] = 1; specks[383:386, 450] = 1          # across the seams of 128-row windows too
     for mask in (empty, wall, specks, edges, _body(pkg, nx, ny, "naca4412", 15.0)):
-        f, m, _ = _run(pkg, mask, [8, 9], 0.58, 0.06, True, 12)
-        fr, mr = oracle_c.run(mask, 17, 0.58, 0.06, np.float32)
-        assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr))
+        for dtype, sites in ((np.float32, 4), (np.float32, 2), (np.float64, 2)):
+            f, m, _ = _run(pkg, mask, [8, 9], 0.58, 0.06, True, 12, sites, np.dtype(dtype).name)
+            fr, mr = oracle_c.run(mask, 17, 0.58, 0.06, dtype)
+            assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr)), (dtype, sites)
 
 
 def test_fused_low_tau_clamp_and_mask_change(pkg, oracle_c):
     nx, ny = 512, 256
     m1, m2 = _body(pkg, nx, ny, "naca4412", 20.0), _body(pkg, nx, ny, "naca4412", 5.0)
-    with pkg.Engine(nx, ny) as e:
+    fr, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float32)
+    fr, mr = oracle_c.run(m2, 100, 0.5004, 0.09, np.float32, f=fr)
+    for sites in (4, 2):
+        with pkg.Engine(nx, ny) as e:
+            e.set_option("fuse_sites", sites)
+            e.set_option("fuse_steps", 2)
+            e.set_mask(m1); e.init_equilibrium(0.10); e.step(300, 0.5004, 0.10)
+            e.set_mask(m2); e.step(100, 0.5004, 0.09)
+            f, m = e.read_f(), e.read_macro()
+            events = e.clamp_events()
+        assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr)), sites
+    fr64, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float64)
+    fr64, mr64 = oracle_c.run(m2, 100, 0.5004, 0.09, np.float64, f=fr64)
+    with pkg.Engine(nx, ny, dtype="float64") as e:
         e.set_option("fuse_steps", 2)
         e.set_mask(m1); e.init_equilibrium(0.10); e.step(300, 0.5004, 0.10)
         e.set_mask(m2); e.step(100, 0.5004, 0.09)
-        f, m = e.read_f(), e.read_macro()
-        events = e.clamp_events()
-    fr, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float32)
-    fr, mr = oracle_c.run(m2, 100, 0.5004, 0.09, np.float32, f=fr)
-    assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr))
+        assert e.get_option("fuse_active") == 1.0
+        assert bits_equal(e.read_f(), fr64) and all(bits_equal(a, b) for a, b in zip(e.read_macro(), mr64))
     # the clamp-event diagnostic (html:344-350) counted on the oracle's macro state
     fluid = m2 == 0
     rho, ux, uy = (a.astype(np.float64) for a in mr)
@@ -108,12 +128,21 @@ def test_fused_toggle_midrun_and_4096(pkg):
 def test_fused_not_available(pkg):
     with pkg.Engine(256, 128, dtype="float64") as e:
         with pytest.raises(pkg.WTError):
-            e.set_option("fuse_steps", 2)
-    with pkg.Engine(256, 130) as e:
+            e.set_option("fuse_sites", 4)           # fp64 vectors hold two sites
+        e.set_option("fuse_steps", 2)
+    with pkg.Engine(256, 129) as e:                 # odd NY: no vector width divides it
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_steps", 2)
         with pytest.raises(pkg.WTError):
             e.set_option("no_such_option", 1)
+    with pkg.Engine(256, 130) as e:                 # NY % 4 != 0: two sites per lane only
+        with pytest.raises(pkg.WTError):
+            e.set_option("fuse_sites", 4)
+        with pytest.raises(pkg.WTError):
+            e.set_option("fuse_sites", 3)
+        e.set_option("fuse_steps", 2)
+        e.set_mask(np.zeros((130, 256), np.uint8)); e.init_equilibrium(0.06); e.step(4, 0.58, 0.06)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_sites") == 2
     with pkg.Engine(64, 64) as e:               # eligible but tiny: a plan with few units still works
         e.set_option("fuse_steps", 2)
         e.set_mask(np.zeros((64, 64), np.uint8)); e.init_equilibrium(0.06); e.step(6, 0.58, 0.06)
@@ -146,22 +175,27 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
         assert float(np.hypot(ux, uy).max()) <= 0.35 * (1 + 1e-6)          # html:344-350 clamp bounds
 
 
-@pytest.mark.parametrize("nranks,halo,nx,ny,chunks", [
-    (2, 4, 512, 256, [1, 2, 3, 8, 21]),
-    (3, 7, 768, 512, [40]),
-    (4, 16, 2048, 512, [33, 18]),
-    (2, 1, 512, 256, [9]),              # halo 1: never two exact ghost columns -> single steps only
-    (8, 16, 4096, 256, [50]),
+@pytest.mark.parametrize("nranks,halo,nx,ny,chunks,dtype,sites", [
+    (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 4),
+    (3, 7, 768, 512, [40], "float32", 4),
+    (4, 16, 2048, 512, [33, 18], "float32", 4),
+    (2, 1, 512, 256, [9], "float32", 4),              # halo 1: never two exact ghost columns -> single steps only
+    (8, 16, 4096, 256, [50], "float32", 4),
+    (4, 16, 2048, 512, [33, 18], "float32", 2),
+    (3, 7, 768, 512, [40], "float64", 2),
+    (8, 16, 4096, 256, [50], "float32", 0),           # automatic choice
 ])
-def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks):
+def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks, dtype, sites):
     """Two-steps-per-launch on column slabs (in-process transport): a pair needs two exact ghost
     columns, refresh steps stay single; results equal the plain single lattice bit for bit."""
     mask = _body(pkg, nx, ny, "naca2412", 7.0)
-    f0, m0, _ = _run(pkg, mask, chunks, 0.58, 0.06, False)
-    es = [pkg.Engine(nx, ny, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    f0, m0, _ = _run(pkg, mask, chunks, 0.58, 0.06, False, dtype=dtype)
+    es = [pkg.Engine(nx, ny, rank=r, nranks=nranks, halo=halo, dtype=dtype) for r in range(nranks)]
     try:
         pkg.Engine.link_local(es)
         for e in es:
+            if sites:
+                e.set_option("fuse_sites", sites)
             e.set_option("fuse_steps", 2)
             e.set_mask(mask); e.init_equilibrium(0.06)
         assert any(e.get_option("fuse_active") == 1.0 for e in es)
@@ -184,9 +218,15 @@ def test_fuse_auto_only_where_it_pays(pkg):
             e.set_option("fuse_steps", 1)
             e.set_mask(np.zeros((e.ny, e.nx_global), np.uint8)); e.init_equilibrium(0.06)
         assert small.get_option("fuse_active") == 0.0 and big.get_option("fuse_active") == 1.0
+        assert big.get_option("fuse_sites") == 2          # 8 columns per 256-row unit: the 128-row windows are chosen
         small.set_option("fuse_steps", 2)
         assert small.get_option("fuse_active") == 1.0
         small.step(6, 0.58, 0.06); big.step(6, 0.58, 0.06)
+    with pkg.Engine(4096, 4096) as wide, pkg.Engine(544, 4096) as slab, pkg.Engine(4096, 2048, dtype="float64") as f64:
+        for e in (wide, slab, f64):
+            e.set_mask(np.zeros((e.ny, e.nx_global), np.uint8)); e.init_equilibrium(0.06)
+            assert e.get_option("fuse_active") == 1.0     # the default
+        assert (wide.get_option("fuse_sites"), slab.get_option("fuse_sites"), f64.get_option("fuse_sites")) == (4, 2, 2)
 
 
 def test_set_mask_stays_interactive(pkg):

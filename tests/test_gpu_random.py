@@ -38,12 +38,14 @@ def test_random_case(pkg, oracle_c, seed):
     steps = [int(v) for v in rng.integers(1, 14, size=3)]
     mask = _random_mask(rng, nx, ny)
     ref_f, ref_m = oracle_c.run(mask, sum(steps), tau, u0, np.dtype(dtype))
-    for fuse in (False, True):
+    for fuse in (0, 4, 2):                            # single steps; marching kernel with 4 / 2 sites per lane
         with pkg.Engine(nx, ny, dtype=dtype) as e:
+            e.set_option("fuse_steps", 0)
             if fuse:
-                if dtype != "float32" or ny % 4:
+                if ny % fuse or nx < 8 or (dtype == "float64" and fuse == 4):
                     continue
                 e.set_option("fuse_chunk", int(rng.integers(1, 40)))
+                e.set_option("fuse_sites", fuse)
                 e.set_option("fuse_steps", 2)
             e.set_mask(mask); e.init_equilibrium(u0)
             for n in steps:

@@ -16,6 +16,7 @@
 #include "../airfoil-cfd-tool_amd/csrc/step_march.hpp"
 
 using namespace wt;
+typedef MV<float, 4> V4;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 struct Lattice {
@@ -32,7 +33,7 @@ struct Lattice {
 // MODE 3: as 2 but a window-major ("tiled") address map: a wave's stream is sequential in memory
 // MODE 4: as 0/1 but aligned loads only (shifts would be done in registers)
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
+__global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams<float> p)
 {
     const Geom &g = p.g;
     const int lane = threadIdx.x & 63;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
     if ((MODE == 2 || MODE == 3) && w >= g.ny / 256) return;
     const int row0 = (MODE == 2 || MODE == 3) ? w * 256 : w * 252;
     const int j0 = row0 + lane * 4;
-    MarchAddr a;
+    MarchAddr<float, 4> a;
     a.rs = march_rsrc(p.fs, p.lat_bytes); a.rd = march_rsrc(p.fd, p.lat_bytes);
     a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
     a.voff = (MODE == 3) ? (unsigned)lane * 16u : (unsigned)j0 * 4u;
@@ -56,9 +57,9 @@ __global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
     };
     auto load9 = [&](int col, V4 (&x)[9]) {
         if (MODE >= 2) {
-            x[0] = bload(a.rs, a.voff, off(0, col)); x[1] = bload(a.rs, a.voff, off(1, col - 1)); x[3] = bload(a.rs, a.voff, off(3, col + 1));
-            x[2] = bload(a.rs, a.voff, off(2, col)); x[5] = bload(a.rs, a.voff, off(5, col - 1)); x[6] = bload(a.rs, a.voff, off(6, col + 1));
-            x[4] = bload(a.rs, a.voff, off(4, col)); x[7] = bload(a.rs, a.voff, off(7, col + 1)); x[8] = bload(a.rs, a.voff, off(8, col - 1));
+            x[0] = bload<float, 4>(a.rs, a.voff, off(0, col)); x[1] = bload<float, 4>(a.rs, a.voff, off(1, col - 1)); x[3] = bload<float, 4>(a.rs, a.voff, off(3, col + 1));
+            x[2] = bload<float, 4>(a.rs, a.voff, off(2, col)); x[5] = bload<float, 4>(a.rs, a.voff, off(5, col - 1)); x[6] = bload<float, 4>(a.rs, a.voff, off(6, col + 1));
+            x[4] = bload<float, 4>(a.rs, a.voff, off(4, col)); x[7] = bload<float, 4>(a.rs, a.voff, off(7, col + 1)); x[8] = bload<float, 4>(a.rs, a.voff, off(8, col - 1));
         } else march_load_stream(a, col, x);
     };
     V4 in[9], mac[3];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_march_copy(MarchParams p)
         load9((c + 2 <= ib) ? c + 2 : c + 1, nxt);
         {
 #pragma unroll
-            for (int k = 0; k < 9; k++) bstore(a.rd, a.voff, off(k, c), in[k]);
+            for (int k = 0; k < 9; k++) bstore<float, 4>(a.rd, a.voff, off(k, c), in[k]);
         }
 #pragma unroll
         for (int k = 0; k < 9; k++) in[k] = nxt[k];
@@ -84,7 +85,7 @@ struct DevPlan { MarchUnit *plain = nullptr, *body = nullptr; int nplain = 0, nb
 // straddle window seams); 2: window-major
 static DevPlan upload_plan(const Lattice &L, long target_units, int max_cost = 0, double alpha = 1.0, int order = 0)
 {
-    MarchPlan pl = build_march_plan(L.hwcls.data(), L.g, target_units, max_cost, alpha);
+    MarchPlan pl = build_march_plan(L.hwcls.data(), L.g, 256, target_units, max_cost, alpha);
     if (order == 1) {
         // group units by chunk start (ia): sequence of chunks; within a chunk, windows ascending
         std::vector<std::vector<MarchUnit>> chunks;
@@ -116,7 +117,7 @@ static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
     Lattice L; L.nx = nx; L.ny = ny;
     Geom &g = L.g; g.nxl = nx; g.ny = ny; g.gi0 = 0; g.nx_g = nx; g.pitch = ((long)ny + 255) / 256 * 256;
     g.plane = (((long)(nx + 2) * g.pitch * 4 + 4095) / 4096 * 4096 + 17408) / 4;
-    L.tpc = (int)(g.pitch / 256); L.nwin = march_nwin(ny);
+    L.tpc = (int)(g.pitch / 256); L.nwin = march_nwin(ny, 256);
     L.lat = (size_t)9 * g.plane * 4;
     CK(hipMalloc(&L.f0, L.lat)); CK(hipMalloc(&L.f1, L.lat)); CK(hipMalloc(&L.f2, L.lat)); CK(hipMalloc(&L.f3, L.lat));
     CK(hipMalloc(&L.macro, (size_t)3 * nx * g.pitch * 4)); CK(hipMalloc(&L.macro2, (size_t)3 * nx * g.pitch * 4));
@@ -146,11 +147,11 @@ static Lattice make_lattice(int nx, int ny, int body, hipStream_t st)
     CK(hipMemcpy(L.mask, L.hmask.data(), L.hmask.size(), hipMemcpyHostToDevice));
     classify_tiles(L.mask, L.tiles, g, L.tpc, st);
     const long nt = (long)(nx + 2) * L.nwin;
-    hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, L.mask, L.wcls, g, L.nwin);
+    hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, L.mask, L.wcls, g, L.nwin, 256);
     CK(hipMemsetAsync(L.bcode, 0, (size_t)(nx + 2) * g.pitch, st));
     hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, st, L.mask, L.bcode, g);
     CK(hipMalloc(&L.seam_plain, (size_t)std::max(1, L.nwin - 1) * nx));
-    if (L.nwin > 1) { const long nth = (long)(L.nwin - 1) * nx; hipLaunchKernelGGL(k_seam_flags, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const uint8_t *)L.mask, (const uint8_t *)L.bcode, L.seam_plain, g, L.nwin); }
+    if (L.nwin > 1) { const long nth = (long)(L.nwin - 1) * nx; hipLaunchKernelGGL(k_seam_flags, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, (const uint8_t *)L.mask, (const uint8_t *)L.bcode, L.seam_plain, g, L.nwin, 256); }
     CK(hipStreamSynchronize(st)); CK(hipGetLastError());
     L.hwcls.resize((size_t)(nx + 2) * L.nwin);
     CK(hipMemcpy(L.hwcls.data(), L.wcls, L.hwcls.size(), hipMemcpyDeviceToHost));
@@ -172,12 +173,12 @@ static void free_lattice(Lattice &L)
     (void)hipFree(L.f0); (void)hipFree(L.f1); (void)hipFree(L.f2); (void)hipFree(L.f3); (void)hipFree(L.macro); (void)hipFree(L.macro2); (void)hipFree(L.mask); (void)hipFree(L.tiles); (void)hipFree(L.bcode); (void)hipFree(L.wcls); (void)hipFree(L.halo); (void)hipFree(L.seams); (void)hipFree(L.seam_plain);
 }
 
-static MarchParams march_params(const Lattice &L, const float *a, float *b, float *macro, const MarchUnit *units, int nunits, float tau, float rtau, float U0, int rev)
+static MarchParams<float> march_params(const Lattice &L, const float *a, float *b, float *macro, const MarchUnit *units, int nunits, float tau, float rtau, float U0, int rev)
 {
-    MarchParams p;
+    MarchParams<float> p;
     p.fs = a; p.fd = b; p.macro = macro; p.mask = L.mask; p.bcode = L.bcode; p.wcls = L.wcls; p.halo = L.halo; p.seams = L.seams; p.g = L.g; p.nwin_total = L.nwin;
     p.units = units; p.nunits = nunits; p.lat_bytes = (unsigned)L.lat;
-    p.fdv.tau = tau; p.fdv.rtau = rtau; p.U0 = U0; p.rev = rev;
+    p.fdv.tau = tau; p.fdv.rtau = rtau; p.tau = tau; p.U0 = U0; p.rev = rev;
     return p;
 }
 static int g_lds_bytes = 0;
@@ -190,11 +191,11 @@ static void march_pass(const Lattice &L, const DevPlan &d, const float *a, float
     if (L.nwin > 1) {
         const long nth = (long)(L.nwin - 1) * L.g.nxl;
         const FastDiv fdv{tau, rtau};
-        if (g_seams_valid) hipLaunchKernelGGL((k_halo_from_seams<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, fdv, U0);
-        else hipLaunchKernelGGL((k_halo_rows<FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, fdv, U0);
+        if (g_seams_valid) hipLaunchKernelGGL((k_halo_from_seams<float, FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0);
+        else hipLaunchKernelGGL((k_halo_rows<float, FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0);
     }
     if (sb != st) { CK(hipEventRecord(ev0, st)); CK(hipStreamWaitEvent(sb, ev0, 0)); }
-    if (d.nbody) hipLaunchKernelGGL((k_march<EMIT, FD>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), g_lds_bytes, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
+    if (d.nbody) hipLaunchKernelGGL((k_march<float, 4, EMIT, FD>), dim3((unsigned)((d.nbody + 3) / 4)), dim3(256), g_lds_bytes, sb, march_params(L, a, b, macro, d.body, d.nbody, tau, rtau, U0, rev));
     if (sb != st) { CK(hipEventRecord(ev1, sb)); CK(hipStreamWaitEvent(st, ev1, 0)); }
 }
 
@@ -301,8 +302,8 @@ int main(int argc, char **argv)
     std::vector<Var> vs;
     std::vector<DevPlan> plans; plans.reserve(256);
     vs.push_back({"k_step x2 (production)", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(L.f1, b, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
-    vs.push_back({"k_halo_rows only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_rows<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, fdv, U0); }, {}, 1});
-    vs.push_back({"k_halo_from_seams only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_from_seams<1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, fdv, U0); }, {}, 1});
+    vs.push_back({"k_halo_rows only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_rows<float, 1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0); }, {}, 1});
+    vs.push_back({"k_halo_from_seams only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_from_seams<float, 1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0); }, {}, 1});
     for (int force_body : {0, 2}) for (int sv : {0, 1}) {
         plans.push_back(upload_plan(L0, 4096)); DevPlan *d0 = &plans.back();
         const std::string tag = std::string(sv ? "[seam buffer] " : "[gather] ") + (force_body ? "[body loop only] " : "");
