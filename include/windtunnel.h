@@ -85,13 +85,18 @@ const char *wt_version(void);
 /* Tuning knobs (no counterpart in the reference).
  *   "fuse_steps" (0 / 1 = where it pays / 2 = always): advance TWO steps per pass over the lattice — a marching kernel
  *       that keeps the intermediate step in registers, body / inlet / outlet included (csrc/step_march.hpp); results are
- *       bit-identical either way.  fp32 handles (whole lattices and slabs) with NY % 4 == 0 and a lattice below 4 GiB.
- *       Default: 1 (environment WT_FUSE2=0|1|2 overrides at wt_create); handles that are not eligible stay on the single-step kernel.
+ *       bit-identical either way.  fp32 and fp64 handles (whole lattices and slabs) with an even NY, at least 8 local
+ *       columns and a lattice below 4 GiB.  Default: 1 (environment WT_FUSE2=0|1|2 overrides at wt_create); handles
+ *       that are not eligible, or too small for it to pay, stay on the single-step kernel.
+ *   "fuse_sites" (0 = automatic / 2 / 4): sites per lane of the marching kernel = window height / 64.  fp64 handles
+ *       use 2; fp32 handles 4 (256-row windows) on wide lattices and 2 (128-row windows, twice the units) on narrow
+ *       ones such as column slabs; 4 needs NY % 4 == 0.
  *   "fuse_chunk": cost limit of one marching unit in columns (0 = whole resident rounds of units, the default).
  *   "fast_div" (default 1): divide by tau through a reciprocal and two fused multiply-adds where an exhaustive
  *       on-device check over all 2^23 significands has PROVED the sequence equal to the IEEE quotient for this tau
  *       (csrc/d2q9.hpp); 0 keeps the IEEE division everywhere.  Bit-identical either way.
- * wt_get_option also reports "fuse_active", "fuse_units", "fuse_tiles_general", "fast_div_active". */
+ *       fp32 only (fp64 always divides in IEEE arithmetic).
+ * wt_get_option also reports "fuse_active", "fuse_units", "fuse_sites" (in use), "fuse_tiles_general", "fast_div_active". */
 int wt_set_option(wt_handle *h, const char *name, double value);
 int wt_get_option(const wt_handle *h, const char *name, double *value);
 
