@@ -213,49 +213,46 @@ __global__ __launch_bounds__(256) void k_halo_rows(const T *__restrict__ fs, con
 }
 
 // The same table from the seam buffer S that the PREVIOUS marching pass wrote beside the lattice it produced (valid
-// only then: the library tracks it).  Neighbouring threads read neighbouring 48-element records: coalesced, 13 MB instead
-// of a 130 MB gather.  Sites near the body / on the inlet and outlet columns fall back to site_step1 on the lattice.
+// only then: the library tracks it).  One thread per (seam, column, SIDE): side 0 = the row below the seam (its step-1
+// populations 2,5,6 move up), side 1 = the row above it (4,7,8 move down) — twice the threads of k_halo_rows, because
+// this kernel is latency-bound (a 4096^2 lattice has only 61 440 (seam, column) pairs).  Neighbouring threads read
+// neighbouring 48-element records: coalesced, 13 MB instead of a 130 MB gather.  Sites near the body / on the inlet and
+// outlet columns fall back to site_step1 on the lattice.
 template <typename T, int FD>
 __global__ __launch_bounds__(256) void k_halo_from_seams(const T *__restrict__ fs, const T *__restrict__ seams, const uint8_t *__restrict__ mask,
                                                          const uint8_t *__restrict__ seam_plain, T *__restrict__ halo, Geom g, int nwin, int win,
                                                          FastDiv fdv, T tau, T U0)
 {
     const long total = (long)(nwin - 1) * g.nxl;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long t2 = (long)blockIdx.x * 256 + threadIdx.x;
+    const int side = (int)(t2 & 1);
+    const long t = t2 >> 1;
     if (t >= total) return;
     const int x = (int)(t % g.nxl);
     const int b = 1 + (int)(t / g.nxl);
-    const int j = win * b - 1;
-    if (j >= g.ny) return;
-    const T *s = fs + g.pitch;
-    const uint8_t *m = mask + g.pitch;
-    T lo[9], hi[9];
-    const bool two = (j + 1 < g.ny);
-    const bool plain = seam_plain[t] != 0;
-    if (plain) {
-        T a[9], d[9], rho, ux, uy;
+    const int j = win * b - 1 + side;                // side 0: row win*b-1, side 1: row win*b
+    T o[9];
+    if (j >= g.ny) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = T(0);
+    } else if (seam_plain[t] != 0) {
+        T a[9], rho, ux, uy;
         const T *rec = seams + ((long)b * (g.nxl + 2) + x + 1) * 48;
 #pragma unroll
         for (int k = 0; k < 9; k++) {
+            // record of the upstream column: slot k = {row win*b-2, row win*b-1 | +24: row win*b, row win*b+1}; the input of
+            // row r for direction k is row r - ey_k
             const T *r = rec - (long)ex_of(k) * 48 + 2 * k;
-            typedef T t2 __attribute__((ext_vector_type(2)));
-            const t2 below = *reinterpret_cast<const t2 *>(r);           // rows WIN*b-2, WIN*b-1
-            const t2 above = *reinterpret_cast<const t2 *>(r + 24);      // rows WIN*b, WIN*b+1
-            const T q[4] = {below[0], below[1], above[0], above[1]};
-            a[k] = q[1 - ey_of(k)];      // input of row WIN*b-1
-            d[k] = q[2 - ey_of(k)];      // input of row WIN*b
+            const int q = 1 + side - ey_of(k);       // 0..3 over the four rows around the seam
+            a[k] = r[(q >> 1) * 24 + (q & 1)];
         }
-        collide_t<T, FD>(a, fdv, tau, lo, rho, ux, uy);
-        collide_t<T, FD>(d, fdv, tau, hi, rho, ux, uy);
+        collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
     } else {
-        site_step1<T, FD>(s, m, g, x, j, fdv, tau, U0, lo);
-        if (two) site_step1<T, FD>(s, m, g, x, j + 1, fdv, tau, U0, hi);
-        else { for (int k = 0; k < 9; k++) hi[k] = T(0); }
+        site_step1<T, FD>(fs + g.pitch, mask + g.pitch, g, x, j, fdv, tau, U0, o);
     }
     typedef T t4 __attribute__((ext_vector_type(4)));
     t4 *out = reinterpret_cast<t4 *>(halo + ((long)b * (g.nxl + 2) + x + 1) * 8);
-    out[0] = t4{lo[2], lo[5], lo[6], T(0)};
-    out[1] = t4{hi[4], hi[7], hi[8], T(0)};
+    out[side] = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
 }
 
 // ------------------------------------------------------------------------------------------------

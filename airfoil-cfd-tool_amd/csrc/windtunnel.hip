@@ -756,7 +756,7 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
         const uint8_t *mk = h->mask, *sp = h->seam_plain;
         T *ht = reinterpret_cast<T *>(h->halo_tab);
         if (h->seams_valid)     // the previous pass left the seam rows of this lattice in `seams`: coalesced loads
-            hipLaunchKernelGGL((k_halo_from_seams<T, FD>), grid, block, 0, st, p.fs, (const T *)p.seams, mk, sp, ht, g, h->n_win, 64 * S, p.fdv, p.tau, p.U0);
+            hipLaunchKernelGGL((k_halo_from_seams<T, FD>), dim3((unsigned)((2 * nth + 255) / 256)), block, 0, st, p.fs, (const T *)p.seams, mk, sp, ht, g, h->n_win, 64 * S, p.fdv, p.tau, p.U0);
         else                    // gather from the lattice (first pass after a single step, an upload, a ghost refresh)
             hipLaunchKernelGGL((k_halo_rows<T, FD>), grid, block, 0, st, p.fs, mk, sp, ht, g, h->n_win, 64 * S, p.fdv, p.tau, p.U0);
     }

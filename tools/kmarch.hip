@@ -191,7 +191,7 @@ static void march_pass(const Lattice &L, const DevPlan &d, const float *a, float
     if (L.nwin > 1) {
         const long nth = (long)(L.nwin - 1) * L.g.nxl;
         const FastDiv fdv{tau, rtau};
-        if (g_seams_valid) hipLaunchKernelGGL((k_halo_from_seams<float, FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0);
+        if (g_seams_valid) hipLaunchKernelGGL((k_halo_from_seams<float, FD>), dim3((unsigned)((2 * nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0);
         else hipLaunchKernelGGL((k_halo_rows<float, FD>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0);
     }
     if (sb != st) { CK(hipEventRecord(ev0, st)); CK(hipStreamWaitEvent(sb, ev0, 0)); }
@@ -303,7 +303,7 @@ int main(int argc, char **argv)
     std::vector<DevPlan> plans; plans.reserve(256);
     vs.push_back({"k_step x2 (production)", [&](const float *a, float *b, int r) { step_columns<float, 3>(a, L.f1, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 0, st); step_columns<float, 3>(L.f1, b, L.macro, L.mask, L.tiles, L.tpc, L.g, 0, nx, tau, U0, false, 1, st); }, {}, 2});
     vs.push_back({"k_halo_rows only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_rows<float, 1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0); }, {}, 1});
-    vs.push_back({"k_halo_from_seams only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_from_seams<float, 1>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0); }, {}, 1});
+    vs.push_back({"k_halo_from_seams only", [&](const float *a, float *b, int r) { const long nth = (long)(L.nwin - 1) * L.g.nxl; const FastDiv fdv{tau, 1.0f / tau}; hipLaunchKernelGGL((k_halo_from_seams<float, 1>), dim3((unsigned)((2 * nth + 255) / 256)), dim3(256), 0, st, a, (const float *)L.seams, (const uint8_t *)L.mask, (const uint8_t *)L.seam_plain, L.halo, L.g, L.nwin, 256, fdv, tau, U0); }, {}, 1});
     for (int force_body : {0, 2}) for (int sv : {0, 1}) {
         plans.push_back(upload_plan(L0, 4096)); DevPlan *d0 = &plans.back();
         const std::string tag = std::string(sv ? "[seam buffer] " : "[gather] ") + (force_body ? "[body loop only] " : "");
