@@ -270,6 +270,7 @@ struct MarchParams {
     const uint8_t *bcode;      // bounce codes, column 0 first
     const uint8_t *wcls;       // window-tile classes [nwin][nxl + 2]
     const T *halo;             // H[nwin + 1][nxl + 2][8], see k_halo_rows
+    const T *halo2;            // three-step passes only (step_march3.hpp): the level-2 halo table
     T *seams;                  // S[nwin + 1][nxl + 2][2][24]: the rows around every window seam of the DESTINATION lattice, see k_halo_from_seams
     const MarchUnit *units;
     int nunits;
@@ -871,12 +872,13 @@ struct MarchPlan {
 // COST — a FAST column costs 1, any other column 1 + alpha (its step 1 waits for nine more loads) — such that
 // the total is at most `target_units` (a multiple of `slots` chosen by the caller), or, when max_cost > 0, into
 // units of at most max_cost (tests, experiments).
-static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int win, long target_units, int max_cost = 0, double alpha = 1.0)
+static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int win, long target_units, int max_cost = 0, double alpha = 1.0,
+                                         const MarchRange *range = nullptr)
 {
     MarchPlan pl;
     const int nwin = march_nwin(g.ny, win), ld = g.nxl + 2;
     pl.nwin = nwin;
-    const MarchRange r = march_range(g);
+    const MarchRange r = range ? *range : march_range(g);
     const int ncol = r.i_end - r.i_begin;
     if (ncol <= 0) return pl;
     std::vector<double> wcost((size_t)nwin, 0.0);

@@ -1,0 +1,391 @@
+// step_march3.hpp — THREE lattice steps per pass (fp32, 2 sites per lane, 128-row windows).
+//
+// Why: the SQ counters of the two-step kernel (profiles/r02_c_sq_counters.txt) show its vector-memory issue stalled on a
+// full texture-addresser command FIFO for about as many cycles as the kernel runs, with the vector ALU 30 % busy — it is
+// bound by the per-CU load/store path (~10 B/clk/CU of L1-miss traffic, the same limit k_step sits on), not by
+// arithmetic.  The only lever left is bytes per step: a pass that advances T steps moves 9 (L + 2(T-1))/L + 9 words
+// per site instead of 18 T.  T = 3 needs one more level of register-resident intermediate columns (21 vectors); with 2
+// sites per lane that fits the 256-VGPR budget of two waves per SIMD (T = 3 with 4 sites per lane, or T = 4, does not).
+//
+// Pipeline of one wave (window w, columns [ia, ib)), iteration x:
+//     level 1 of column x      <- STEP_FS on the nine streamed vectors of column x        (march_step1, as in the two-step kernel)
+//     level 2 of column x - 1  <- STEP_FS on level 1 of columns x-2, x-1, x               (march_stage)
+//     level 3 of column x - 2  <- STEP_FS on level 2 of columns x-3, x-2, x-1 -> stored   (march_stage)
+// The rows just outside the window come from two halo tables per pass: H1 (level-1 values) and H2 (level-2 values),
+// built by k_halo3_level1 / k_halo3_level2 from the seam buffer S3 the previous pass wrote (four rows on either side
+// of every seam) or, when that is stale, from the lattice.
+// Every site goes through the arithmetic of k_step three times: results are bit-identical to three single steps.
+#pragma once
+#include "step_march.hpp"
+
+namespace wt {
+
+static constexpr int M3_S = 2;              // sites per lane
+static constexpr int M3_WIN = 64 * M3_S;    // window height
+static constexpr int M3_SREC = 80;          // S3 record: 2 halves x (9 slots x 4 rows + one pad slot) floats
+static constexpr int M3_SHALF = 40;
+static constexpr int M3_L1REC = 36;         // level-1 table: 4 rows x 9 directions per (seam, column)
+
+// ------------------------------------------------------------------------------------------------
+// once per pass: the two halo tables
+// ------------------------------------------------------------------------------------------------
+// L1T[(b * (nxl+2) + x + 1)][r4][k] = level-1 population k of site (x, 128 b - 2 + r4), r4 = 0..3, seam b = 1 .. nwin-1.
+// One thread per (seam, column, row).  Plain interior fluid sites take their nine inputs from the seam buffer
+// (record of the upstream column: rows 128 b - 4 .. 128 b + 3 of the lattice this pass reads) when it is valid;
+// everything else — and every site when it is not — goes through site_step1 on the lattice.
+template <int FD>
+__global__ __launch_bounds__(256) void k_halo3_level1(const float *__restrict__ fs, const float *__restrict__ seams3, const uint8_t *__restrict__ mask,
+                                                      const uint8_t *__restrict__ bcode, float *__restrict__ l1t, Geom g, int nwin, int use_seams,
+                                                      FastDiv fdv, float U0)
+{
+    const long total = (long)(nwin - 1) * g.nxl * 4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int r4 = (int)(t & 3);
+    const long t1 = t >> 2;
+    const int x = (int)(t1 % g.nxl);
+    const int b = 1 + (int)(t1 / g.nxl);
+    const int j = M3_WIN * b - 2 + r4;
+    const uint8_t *m = mask + g.pitch;
+    float o[9];
+    if (j >= g.ny) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = 0.0f;
+    } else {
+        const long c = (long)x * g.pitch + j;
+        const int gi = x + g.gi0;
+        const bool plain = use_seams && gi > 0 && gi < g.nx_g - 1 && j > 0 && j < g.ny - 1 && m[c] == 0 && bcode[c] == 0;
+        if (plain) {
+            float a[9], rho, ux, uy;
+            const float *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int q = 2 + r4 - ey_of(k);             // row j - ey_k relative to row 128 b - 4: 1..6
+                a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
+            }
+            collide_t<float, FD>(a, fdv, fdv.tau, o, rho, ux, uy);
+        } else {
+            site_step1<float, FD>(fs + g.pitch, m, g, x, j, fdv, fdv.tau, U0, o);
+        }
+    }
+    float *dst = l1t + (((long)b * (g.nxl + 2) + x + 1) * 4 + r4) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) dst[k] = o[k];
+}
+
+// H1 / H2[(b * (nxl+2) + x + 1) * 8 + side * 4 + {0,1,2}]: side 0 = populations 2,5,6 of row 128 b - 1 (they move up into window
+// b), side 1 = populations 4,7,8 of row 128 b (they move down into window b - 1) — H1 at level 1 (copied out of L1T), H2 at
+// level 2: STEP_FS once more, every branch in the reference's order (html:283-360), on the level-1 table.
+template <int FD>
+__global__ __launch_bounds__(256) void k_halo3_level2(const float *__restrict__ l1t, const uint8_t *__restrict__ mask, float *__restrict__ h1,
+                                                      float *__restrict__ h2, Geom g, int nwin, FastDiv fdv, float U0)
+{
+    const long total = (long)(nwin - 1) * g.nxl * 2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int side = (int)(t & 1);
+    const long t1 = t >> 1;
+    const int x = (int)(t1 % g.nxl);
+    const int b = 1 + (int)(t1 / g.nxl);
+    const int j = M3_WIN * b - 1 + side;
+    const int idx = 1 + side;                                   // row of L1T holding row j
+    const uint8_t *m = mask + g.pitch;
+    const float *base = l1t + (((long)b * (g.nxl + 2) + x + 1) * 4 + idx) * 9;
+    auto get = [&](int k, int dx, int dy) { return base[((long)dx * 4 + dy) * 9 + k]; };
+    float o[9];
+    if (j >= g.ny) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = 0.0f;
+    } else {
+        const long c = (long)x * g.pitch + j;
+        const int gi = x + g.gi0;
+        if (m[c]) {                                                    // html:287-294 solid
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k] = get(opp_of(k), 0, 0);
+        } else if (gi == g.nx_g - 1) {                                 // html:301-312 outlet
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k] = get(k, -1, 0);
+        } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
+            feq_all<float>(1.0f, U0, 0.0f, o);
+        } else {                                                       // html:324-359 interior fluid
+            float fin[9], rho, ux, uy;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
+                fin[k] = m[src] ? get(opp_of(k), 0, 0) : get(k, -ex_of(k), -ey_of(k));
+            }
+            collide_t<float, FD>(fin, fdv, fdv.tau, o, rho, ux, uy);
+        }
+    }
+    const long rec = ((long)b * (g.nxl + 2) + x + 1) * 8 + side * 4;
+    const float4 v1 = side ? make_float4(get(4, 0, 0), get(7, 0, 0), get(8, 0, 0), 0.0f) : make_float4(get(2, 0, 0), get(5, 0, 0), get(6, 0, 0), 0.0f);
+    const float4 v2 = side ? make_float4(o[4], o[7], o[8], 0.0f) : make_float4(o[2], o[5], o[6], 0.0f);
+    *reinterpret_cast<float4 *>(h1 + rec) = v1;
+    *reinterpret_cast<float4 *>(h2 + rec) = v2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the marching kernel
+// ------------------------------------------------------------------------------------------------
+typedef MV<float, M3_S> V3;
+
+struct March3Addr {
+    MarchAddr<float, M3_S> a;            // lattice / macro descriptors and offsets (its seam fields are unused here)
+    __amdgpu_buffer_rsrc_t rs3;          // seam buffer S3
+    unsigned voff_lo, voff_hi;           // lanes 0..9: byte offsets of their 16-byte slot in the two half records this window writes
+    float *lds_w, *lds_r;
+};
+
+// one more application of STEP_FS in registers: level k+1 of column c from level k of columns c-1 (populations 1,5,8: m158),
+// c (all nine: Gc) and c+1 (3,6,7 of Gn); `hv` = this column's halo-table word (lanes 0..5)
+template <bool BODY, bool WANT_MACRO, int FD>
+__device__ __forceinline__ void march_stage(const MarchParams<float> &p, int c, int j0, int lane, bool far_win, bool nf, bool allsolid,
+                                            const float (&feq0)[9], const V3 (&m158)[3], const V3 (&Gc)[9], const V3 (&Gn)[9], float hv,
+                                            V3 (&out)[9], V3 (&mac)[3])
+{
+    const Geom &g = p.g;
+    const float hb2 = readlane_t(hv, 0), hb5 = readlane_t(hv, 1), hb6 = readlane_t(hv, 2), ha4 = readlane_t(hv, 3), ha7 = readlane_t(hv, 4),
+                ha8 = readlane_t(hv, 5);
+    V3 fin[9];
+    fin[0] = Gc[0]; fin[1] = m158[0]; fin[3] = Gn[3];
+    fin[2] = m_below(Gc[2], lane, hb2); fin[5] = m_below(m158[1], lane, hb5); fin[6] = m_below(Gn[6], lane, hb6);
+    fin[4] = m_above(Gc[4], lane, ha4); fin[8] = m_above(m158[2], lane, ha8); fin[7] = m_above(Gn[7], lane, ha7);
+    if (BODY) {
+        const int gi = c + g.gi0;
+        if (__builtin_expect(gi <= 0 || nf, 0)) {
+            auto ownc = [&](int k) { return Gc[k]; };
+            uint32_t solid4 = 0, code4 = 0;
+            if (nf) {
+                solid4 = load_site_bytes<M3_S>(p.mask + (long)(c + 1) * g.pitch + j0);
+                code4 = load_site_bytes<M3_S>(p.bcode + (long)c * g.pitch + j0);
+            }
+            const bool any_solid = __ballot(solid4 != 0) != 0ULL;
+            if (gi <= 0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) out[k] = mv_splat<float, M3_S>(feq0[k]);
+                if (WANT_MACRO) { mac[0] = mv_splat<float, M3_S>(1.0f); mac[1] = mv_splat<float, M3_S>(p.U0); mac[2] = mv_splat<float, M3_S>(0.0f); }
+            } else if (allsolid) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) out[k] = Gc[k];        // every site is overwritten by march_solid below
+                if (WANT_MACRO) { mac[0] = mv_splat<float, M3_S>(1.0f); mac[1] = mv_splat<float, M3_S>(0.0f); mac[2] = mv_splat<float, M3_S>(0.0f); }
+            } else {
+                march_bounce<float, M3_S>(fin, code4, ownc);
+                march_collide_general<float, M3_S, FD, WANT_MACRO>(fin, solid4, j0, g.ny, p.fdv, p.tau, p.U0, feq0, out, mac);
+            }
+            if (any_solid && (gi <= 0 || allsolid)) march_solid<float, M3_S, WANT_MACRO>(out, mac, solid4, ownc);
+            return;
+        }
+    }
+    march_collide<float, M3_S, FD, WANT_MACRO>(fin, p.fdv, p.tau, out, mac);
+    if (far_win) march_far_rows<float, M3_S, WANT_MACRO>(j0, g.ny, p.U0, feq0, out, mac);
+}
+
+// nine lattice stores (+ three macro stores) of column `col`, then STAGE the four rows on either side of the window's
+// seams in LDS (lanes 0,1 hold rows 0..3, lanes 62,63 rows 124..127; every lane writes — the others into a scratch area)
+// (`voff_st`: the lane's store offset, or an out-of-range one to drop the column's stores without a branch)
+template <bool EMIT>
+__device__ __forceinline__ void march3_store(const March3Addr &m, unsigned voff_st, int col, const V3 (&out)[9], const V3 (&mac)[3])
+{
+    const MarchAddr<float, M3_S> &a = m.a;
+#pragma unroll
+    for (int k = 0; k < 9; k++) (void)bstore<float, M3_S>(a.rd, voff_st, lat_off(a, k, col, 0), out[k]);
+    if (EMIT) {
+        const unsigned mo = (unsigned)col * a.pitch4;
+#pragma unroll
+        for (int q = 0; q < 3; q++) (void)bstore<float, M3_S>(a.rm, voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(m.lds_w + 4 * k) = make_float2(out[k].v[0], out[k].v[1]);
+}
+struct Seam3 { float4 below, above; };
+__device__ __forceinline__ Seam3 seam3_fetch(const March3Addr &m)
+{
+    Seam3 r;
+    r.below = *reinterpret_cast<const float4 *>(m.lds_r);                  // rows 124..127 of direction `lane`
+    r.above = *reinterpret_cast<const float4 *>(m.lds_r + M3_SHALF);       // rows 0..3
+    return r;
+}
+__device__ __forceinline__ void seam3_flush(const March3Addr &m, int col, const Seam3 &r)
+{
+    const unsigned so = (unsigned)(col + 1) * (unsigned)(M3_SREC * 4);
+    u4v d0, d1;
+    d0.x = __float_as_uint(r.below.x); d0.y = __float_as_uint(r.below.y); d0.z = __float_as_uint(r.below.z); d0.w = __float_as_uint(r.below.w);
+    d1.x = __float_as_uint(r.above.x); d1.y = __float_as_uint(r.above.y); d1.z = __float_as_uint(r.above.z); d1.w = __float_as_uint(r.above.w);
+    __builtin_amdgcn_raw_buffer_store_b128(d0, m.rs3, m.voff_hi, so, 0);        // -> seam w+1, half 0
+    __builtin_amdgcn_raw_buffer_store_b128(d1, m.rs3, m.voff_lo, so, 0);        // -> seam w,   half 1
+    store_data_fence2(d0, d1);
+}
+
+template <bool BODY, bool EMIT, int FD>
+__device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3Addr &m, __amdgpu_buffer_rsrc_t rh1, __amdgpu_buffer_rsrc_t rh2, unsigned hoff,
+                                            int ia, int ib, int uflags, int j0, int lane, bool far_win, unsigned long long nonfast_m,
+                                            unsigned long long solid_m, const float (&feq0)[9])
+{
+    const Geom &g = p.g;
+    const MarchAddr<float, M3_S> &a = m.a;
+#define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 2)) & 1ULL) != 0)
+#define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 2)) & 1ULL) != 0)
+#define STEP1(x, in, G) march_step1<BODY, FD, float, M3_S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+    const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
+    const int xend = outlet ? ib : ib + 1;       // last column whose level 1 is computed (the outlet column itself for the last unit)
+    V3 s1m[3], s1c[9];           // level 1: populations 1,5,8 of column x-2; all nine of column x-1
+    V3 s2m[3], s2c[9];           // level 2: populations 1,5,8 of column x-3; all nine of column x-2
+    V3 in[9], G1[9], G2[9], mac[3];
+    // ---- prologue: level 1 of columns ia-2 and ia-1 (columns left of the inlet do not exist: the inlet column's far-field
+    //      value stands in — never used, the inlet column is a constant at every level)
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s1c[k] = mv_splat<float, M3_S>(feq0[k]); s2c[k] = s1c[k]; }
+    s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+    s2m[0] = s1c[1]; s2m[1] = s1c[5]; s2m[2] = s1c[8];
+    if (!BODY || ia - 2 + g.gi0 >= 0) {
+        march_load_stream(a, ia - 2, in);
+        STEP1(ia - 2, in, s1c);
+    }
+    s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+    if (!BODY || ia - 1 + g.gi0 >= 0) {
+        march_load_stream(a, ia - 1, in);
+        STEP1(ia - 1, in, s1c);
+    }
+    march_load_stream(a, ia, in);
+    int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
+    // The loop body has no branch on the pipeline fill: during the first two iterations (x - 2 < ia) level 3 is computed on
+    // don't-care values and its stores are dropped by an out-of-range offset — a scalar `if` around the stage and its
+    // stores makes hipcc's waitcnt pass drain vmcnt(0) at the merge points of every iteration.
+#pragma unroll 1
+    for (int x = ia; x <= xend; x++) {
+        V3 nxt[9];
+        march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);               // prefetch (last one: harmless re-load)
+        const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
+        const int c1 = x - 1, c2 = x - 2;
+        const float hv1 = halo_load<float>(rh1, hoff, (unsigned)(c1 > 0 ? c1 : 0) * 32u);
+        const float hv2 = halo_load<float>(rh2, hoff, (unsigned)(c2 > 0 ? c2 : 0) * 32u);
+        const Seam3 sp = seam3_fetch(m);                                       // staged by the previous iteration's store
+        STEP1(x, in, G1);                                                      // level 1 of column x
+        // level 2 of column x-1 (a column left of the inlet takes the inlet branch: constants, no memory access)
+        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac);
+        V3 out[9];
+        march_stage<BODY, EMIT, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, out, mac);
+        march3_store<EMIT>(m, has2 ? a.voff_st : p.lat_bytes, has2 ? c2 : 0, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = has2 ? c2 : seam_col;
+        if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
+        s2m[0] = s2c[1]; s2m[1] = s2c[5]; s2m[2] = s2c[8];
+        s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { s2c[k] = G2[k]; s1c[k] = G1[k]; in[k] = nxt[k]; }
+    }
+    if (BODY && outlet) {
+        // Here x = ib = NX-1 (local): s1c = level 1 of NX-2, G1 = level 1 of NX-1, s2c = level 2 of NX-3, G2 = level 2 of NX-2;
+        // level 3 of NX-3 is stored.  The outlet column copies the previous level of column NX-2 (html:301-312):
+        //   level 2 of NX-1 = level 1 of NX-2;  level 3 of NX-1 = level 2 of NX-2;  solid sites: own previous level reversed.
+        const int co = ib;                                   // outlet column
+        uint32_t solid4 = 0;
+        if (NONFAST(co)) solid4 = load_site_bytes<M3_S>(p.mask + (long)(co + 1) * g.pitch + j0);
+        const bool any_solid = __ballot(solid4 != 0) != 0ULL;
+        V3 L2o[9], out[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) L2o[k] = s1c[k];
+        if (any_solid) { auto own1 = [&](int k) { return G1[k]; }; march_solid<float, M3_S, false>(L2o, mac, solid4, own1); }
+        // level 3 of column NX-2
+        V3 t2m[3];
+        t2m[0] = s2c[1]; t2m[1] = s2c[5]; t2m[2] = s2c[8];
+        const float hv2 = halo_load<float>(rh2, hoff, (unsigned)(co - 1) * 32u);
+        Seam3 sp = seam3_fetch(m);
+        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2, out, mac);
+        march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = co - 1;
+        // level 3 of the outlet column
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = G2[k];
+        if (EMIT) march_outlet_macro(G2, mac);
+        if (any_solid) { auto own2 = [&](int k) { return L2o[k]; }; march_solid<float, M3_S, EMIT>(out, mac, solid4, own2); }
+        sp = seam3_fetch(m);
+        march3_store<EMIT>(m, a.voff_st, co, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = co;
+    }
+    seam3_flush(m, seam_col, seam3_fetch(m));
+#undef NONFAST
+#undef ALLSOLID
+#undef STEP1
+}
+
+template <bool EMIT, int FD>
+__global__ __launch_bounds__(256, 2) void k_march3(MarchParams<float> p)
+{
+    const Geom &g = p.g;
+    const int lane = threadIdx.x & 63;
+    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= p.nunits) return;
+    if (p.rev & 1) u = p.nunits - 1 - u;
+    const MarchUnit un = p.units[u];
+    const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
+    const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
+    if (ib <= ia) return;
+    const int row0 = w * M3_WIN;
+    const int j0 = row0 + lane * M3_S;
+    const bool far_win = (w == 0) || (row0 + M3_WIN >= g.ny);
+    March3Addr m;
+    MarchAddr<float, M3_S> &a = m.a;
+    a.rs = march_rsrc(p.fs, p.lat_bytes);
+    a.rd = march_rsrc(p.fd, p.lat_bytes);
+    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
+    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * 4u;
+    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * 4u : p.lat_bytes;
+    a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
+    a.lane = lane;
+    const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 32u;
+    const __amdgpu_buffer_rsrc_t rh1 = march_rsrc(p.halo, hbytes), rh2 = march_rsrc(p.halo2, hbytes);
+    unsigned hoff;
+    {
+        const int hl = lane < 6 ? lane : 0;
+        const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
+        const int slot = hl < 3 ? hl : hl + 1;
+        const int seam = hl < 3 ? w : w + 1;
+        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 8 + slot) * 4u;
+    }
+    {
+        // per wave: below[40] (slot k = rows 124..127 of direction k; lane 62 writes floats 0,1, lane 63 floats 2,3; slot 9 stays
+        // zero), above[40] (lanes 0, 1), then a scratch area for the other 60 lanes
+        __shared__ __attribute__((aligned(16))) float seam_lds[4][2 * M3_SHALF + 176];
+        float *wl = &seam_lds[threadIdx.x >> 6][0];
+        m.lds_w = lane == 62 ? wl : (lane == 63 ? wl + 2 : (lane == 0 ? wl + M3_SHALF : (lane == 1 ? wl + M3_SHALF + 2 : wl + 2 * M3_SHALF + 2 * lane)));
+        m.lds_r = wl + 4 * (lane < 10 ? lane : 0);
+        if (lane < 2 * M3_SHALF / 2) { wl[lane] = 0.0f; wl[lane + M3_SHALF] = 0.0f; }
+        const unsigned sbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * 4);
+        m.rs3 = march_rsrc(p.seams, sbytes);
+        const unsigned rec = (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * 4);
+        m.voff_lo = lane < 10 ? (unsigned)w * rec + (unsigned)(M3_SHALF * 4) + (unsigned)lane * 16u : sbytes;
+        m.voff_hi = lane < 10 ? (unsigned)(w + 1) * rec + (unsigned)lane * 16u : sbytes;
+    }
+    float feq0[9];
+    feq_all<float>(1.0f, p.U0, 0.0f, feq0);
+
+    // classes of columns ia-2 .. ib+1 (lane l <-> column ia-2+l): two 64-bit scalars
+    unsigned long long nonfast_m, solid_m;
+    {
+        const int n = ib - ia + 4;
+        const int col = ia - 2 + lane;
+        uint8_t cls = WC_FAST;
+        if (lane < n && col >= -1 && col <= g.nxl) cls = p.wcls[(long)w * (g.nxl + 2) + col + 1];
+        nonfast_m = __ballot(cls != WC_FAST);
+        solid_m = __ballot(cls == WC_SOLID);
+    }
+    const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= 3 && ib + g.gi0 <= g.nx_g - 3 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
+    if (lean) march_unit3<false, EMIT, FD>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+    else march_unit3<true, EMIT, FD>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+}
+
+// Marched column range of a three-step pass: global edges as in march_range; a local slab edge loses THREE columns of
+// validity per pass, and level 2 of column 1 would need column -2: the two columns next to a local edge are left alone.
+static inline MarchRange march_range3(const Geom &g)
+{
+    MarchRange r;
+    r.i_begin = (g.gi0 == 0) ? 0 : 2;
+    r.outlet_after = (g.gi0 + g.nxl == g.nx_g) ? 1 : 0;
+    r.i_end = r.outlet_after ? g.nxl - 1 : g.nxl - 2;
+    return r;
+}
+
+}  // namespace wt

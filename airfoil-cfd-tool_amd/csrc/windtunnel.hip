@@ -20,6 +20,7 @@
 #include "kernels.hpp"
 #include "step_fast.hpp"
 #include "step_march.hpp"
+#include "step_march3.hpp"
 
 using namespace wt;
 
@@ -94,6 +95,11 @@ struct wt_handle {
     // two-steps-per-launch mode (step_march.hpp)
     bool fuse = false;
     int fuse_sites = 0;                  // option: sites per lane of the marching kernel (0 = automatic; 2 or 4)
+    int fuse_depth = 0;                  // option: steps per pass (0 = automatic; 2 or 3)
+    int march_depth = 0;                 // steps per pass in use (3: step_march3.hpp, fp32 with 2 sites per lane)
+    void *halo2 = nullptr;               // depth 3: level-2 halo table
+    float *l1t = nullptr;                // depth 3: level-1 values of the four rows around every seam
+    long long passes = 0;
     long long march_table_bytes = 0;     // wcls + halo_tab + seams + seam_plain (part of device_bytes)
     int march_s = 0;                     // sites per lane in use (4: fp32 256-row windows; 2: fp64, or fp32 on narrow lattices)
     bool fuse_force = false;             // fuse_steps = 2: also when the lattice is too small for it to pay
@@ -323,6 +329,8 @@ static void free_march_tables(wt_handle *h)
     if (h->halo_tab) { (void)hipFree(h->halo_tab); h->halo_tab = nullptr; }
     if (h->seams) { (void)hipFree(h->seams); h->seams = nullptr; }
     if (h->seam_plain) { (void)hipFree(h->seam_plain); h->seam_plain = nullptr; }
+    if (h->halo2) { (void)hipFree(h->halo2); h->halo2 = nullptr; }
+    if (h->l1t) { (void)hipFree(h->l1t); h->l1t = nullptr; }
     h->seams_valid = false;
     h->n_win = 0;
     h->device_bytes -= h->march_table_bytes;
@@ -331,14 +339,14 @@ static void free_march_tables(wt_handle *h)
 
 // Classes, bounce codes and the unit lists of the current mask for windows of 64 * sites rows.  Everything but the
 // cuts of the column ranges runs on the device; the host reads nwin x (nxl+2) class bytes back.
-static int build_fuse_plan(wt_handle *h, int sites, long target)
+static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
 {
     const Geom &g = h->g;
     const int win = 64 * sites;
     const size_t eb = h->dtype == WT_F32 ? 4 : 8;
     const int nwin = march_nwin(g.ny, win);
     const size_t wbytes = (size_t)nwin * (g.nxl + 2), cbytes = (size_t)(g.nxl + 2) * g.pitch;
-    if (h->n_win != nwin || h->march_s != sites) free_march_tables(h);
+    if (h->n_win != nwin || h->march_s != sites || h->march_depth != depth) free_march_tables(h);
     long long added = 0;
     if (!h->wcls) { HIP_TRY(hipMalloc((void **)&h->wcls, wbytes)); added += (long long)wbytes; }
     if (!h->halo_tab) {
@@ -348,13 +356,21 @@ static int build_fuse_plan(wt_handle *h, int sites, long target)
         added += (long long)hbytes;
     }
     if (!h->seams) {
-        const size_t sbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 48 * eb;
+        const size_t sbytes = (size_t)(nwin + 1) * (g.nxl + 2) * (depth == 3 ? M3_SREC : 48) * eb;
         HIP_TRY(hipMalloc(&h->seams, sbytes));
         HIP_TRY(hipMemsetAsync(h->seams, 0, sbytes, h->s_compute));
         h->seams_valid = false;
         added += (long long)sbytes;
     }
     if (!h->seam_plain && nwin > 1) { HIP_TRY(hipMalloc((void **)&h->seam_plain, (size_t)(nwin - 1) * g.nxl)); added += (long long)(nwin - 1) * g.nxl; }
+    if (depth == 3 && !h->halo2) {
+        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb, lbytes = (size_t)(nwin + 1) * (g.nxl + 2) * M3_L1REC * sizeof(float);
+        HIP_TRY(hipMalloc(&h->halo2, hbytes));
+        HIP_TRY(hipMemsetAsync(h->halo2, 0, hbytes, h->s_compute));
+        HIP_TRY(hipMalloc((void **)&h->l1t, lbytes));
+        HIP_TRY(hipMemsetAsync(h->l1t, 0, lbytes, h->s_compute));
+        added += (long long)(hbytes + lbytes);
+    }
     h->march_table_bytes += added;
     h->device_bytes += added;
     if (!h->bcode) {
@@ -365,6 +381,7 @@ static int build_fuse_plan(wt_handle *h, int sites, long target)
     if (!h->d_nbad) HIP_TRY(hipMalloc((void **)&h->d_nbad, sizeof(unsigned int)));
     h->n_win = nwin;
     h->march_s = sites;
+    h->march_depth = depth;
     const long nt = (long)(g.nxl + 2) * nwin;
     hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->wcls, g, nwin, win);
     hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->bcode, g);
@@ -378,8 +395,8 @@ static int build_fuse_plan(wt_handle *h, int sites, long target)
     HIP_TRY(hipMemcpyAsync(h->host_wcls.data(), h->wcls, wbytes, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
 
-    const MarchRange r = march_range(g);
-    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, 2.0);
+    const MarchRange r = depth == 3 ? march_range3(g) : march_range(g);
+    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, 2.0, &r);
     const size_t total = pl.units.size();
     if (total == 0) return WT_OK;
     if (total > h->units_cap) {
@@ -412,9 +429,11 @@ static long march_target_units(const wt_handle *h, int sites, long slots, bool f
     return target;
 }
 
-// Sites per lane: fp64 always 2 (16-byte vectors); fp32 4 (256-row windows) where that plan has enough units to pay,
-// else 2 (128-row windows: twice the units — narrow lattices such as column slabs); option fuse_sites overrides.
-// The choice depends on the geometry only, so a mask change rebuilds the tables in place.
+// Steps per pass and sites per lane.  fp32: THREE steps per pass (step_march3.hpp, 2 sites per lane) where eligible and not
+// switched off (fuse_depth = 2); otherwise two steps per pass with 4 sites per lane (256-row windows) where that plan has
+// enough units to pay, else 2 (128-row windows: twice the units — narrow lattices such as column slabs).  fp64: two steps,
+// 2 sites (16-byte vectors).  fuse_depth / fuse_sites override.  The choice depends on the geometry only, so a mask change
+// rebuilds the tables in place.
 static int rebuild_fuse_plan(wt_handle *h)
 {
     h->fuse_ready = false;
@@ -425,6 +444,20 @@ static int rebuild_fuse_plan(wt_handle *h)
     long waves = 2;                                                      // resident marching waves per SIMD
     if (const char *e = getenv("WT_MARCH_WAVES")) waves = atoi(e) > 0 ? atoi(e) : 2;
     const long slots = (long)prop.multiProcessorCount * 4 * waves;
+    const bool depth3_ok = h->dtype == WT_F32 && fuse_eligible_s(h, 2) && h->g.nxl >= 16 && h->fuse_depth != 2 && (h->fuse_sites == 0 || h->fuse_sites == 2);
+    if (depth3_ok) {
+        const MarchRange r = march_range3(h->g);
+        const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, M3_WIN);
+        const bool force = h->fuse_force || h->fuse_depth == 3;
+        if (force || h->fuse_chunk > 0 || tiles / slots >= 6) {
+            long target = 2 * slots;
+            if (tiles / target < 12) target = slots;
+            WT_TRY(build_fuse_plan(h, 2, target, 3));
+            h->fuse_ready = h->n_units > 0;
+            return WT_OK;
+        }
+    }
+    if (h->fuse_depth == 3) return WT_OK;
     int order[2] = {4, 2}, n = 2;
     if (h->dtype != WT_F32) { order[0] = 2; n = 1; }
     else if (h->fuse_sites == 2 || h->fuse_sites == 4) { order[0] = h->fuse_sites; n = 1; }
@@ -435,7 +468,7 @@ static int rebuild_fuse_plan(wt_handle *h)
         // 25.9 against 33.5 for single steps)
         const long target = march_target_units(h, order[t], slots, h->fuse_force && t == n - 1, (n == 2 && t == 0) ? 16 : 4);
         if (target == 0) continue;
-        WT_TRY(build_fuse_plan(h, order[t], target));
+        WT_TRY(build_fuse_plan(h, order[t], target, 2));
         h->fuse_ready = h->n_units > 0;
         break;
     }
@@ -461,6 +494,13 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->fuse_sites = (int)value;
         return rebuild_fuse_plan(h);
     }
+    if (strcmp(name, "fuse_depth") == 0) {
+        if (!(value == 0.0 || value == 2.0 || value == 3.0)) return fail(WT_ERR_ARG, "fuse_depth must be 0 (automatic), 2 or 3");
+        if (value == 3.0 && !(h->dtype == WT_F32 && fuse_eligible_s(h, 2) && h->g.nxl >= 16))
+            return fail(WT_ERR_STATE, "fuse_depth 3 needs an fp32 handle with an even NY, at least 16 local columns and a lattice below 4 GiB");
+        h->fuse_depth = (int)value;
+        return rebuild_fuse_plan(h);
+    }
     if (strcmp(name, "fuse_chunk") == 0) {
         if (!(value >= 0.0 && value <= 4096.0)) return fail(WT_ERR_ARG, "fuse_chunk out of range (0 = automatic)");
         h->fuse_chunk = (int)value;
@@ -482,6 +522,7 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_ready ? h->fuse_chunk_used : h->fuse_chunk; return WT_OK; }
     if (strcmp(name, "fuse_units") == 0) { *value = h->n_units; return WT_OK; }
     if (strcmp(name, "fuse_sites") == 0) { *value = h->fuse_ready ? h->march_s : h->fuse_sites; return WT_OK; }
+    if (strcmp(name, "fuse_depth") == 0) { *value = h->fuse_ready ? h->march_depth : h->fuse_depth; return WT_OK; }
     if (strcmp(name, "fuse_tiles_general") == 0) { *value = h->nonfast_tiles; return WT_OK; }   // window-tiles that take the body paths
     if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
@@ -749,6 +790,10 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)((h->steps_done >> 1) & 1);
+    {
+        static const int rev_mode = getenv("WT_MARCH_REV") ? atoi(getenv("WT_MARCH_REV")) : 2;     // experiments: 0 / 1 = fixed order
+        if (rev_mode == 0 || rev_mode == 1) p.rev = rev_mode;
+    }
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // the step-1 populations that cross the window seams
         const long nth = (long)(h->n_win - 1) * g.nxl;
@@ -780,16 +825,71 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     return fd ? step_pair_fused_t<float, 2, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 2, 0>(h, tau, u0, emit);
 }
 
-// a fused pair is possible now: plan ready and (slabs) two exact ghost columns left
-static inline bool can_pair(const wt_handle *h) { return h->fuse_ready && (h->nranks == 1 || h->ghost_valid >= 2); }
+// Three steps in one pass (step_march3.hpp).  A = f[cur] (time t), B = f[1-cur] (receives time t+3).
+template <int FD>
+static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit)
+{
+    const Geom &g = h->g;
+    MarchParams<float> p;
+    p.fs = fptr<float>(h, h->cur);
+    p.fd = fptr<float>(h, 1 - h->cur);
+    p.macro = reinterpret_cast<float *>(h->macro);
+    p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls;
+    p.halo = reinterpret_cast<const float *>(h->halo_tab); p.halo2 = reinterpret_cast<const float *>(h->halo2);
+    p.seams = reinterpret_cast<float *>(h->seams);
+    p.g = g;
+    p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(float));
+    p.nwin_total = h->n_win;
+    p.fdv.tau = (float)tau; p.fdv.rtau = 1.0f / (float)tau;
+    p.tau = (float)tau;
+    p.U0 = (float)u0;
+    p.rev = (int)(h->passes & 1);
+    hipStream_t st = h->s_compute;
+    if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
+        const long n1 = (long)(h->n_win - 1) * g.nxl * 4, n2 = (long)(h->n_win - 1) * g.nxl * 2;
+        hipLaunchKernelGGL((k_halo3_level1<FD>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, p.fs, (const float *)p.seams, (const uint8_t *)h->mask,
+                           (const uint8_t *)h->bcode, h->l1t, g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.U0);
+        hipLaunchKernelGGL((k_halo3_level2<FD>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, (const float *)h->l1t, (const uint8_t *)h->mask,
+                           reinterpret_cast<float *>(h->halo_tab), reinterpret_cast<float *>(h->halo2), g, h->n_win, p.fdv, p.U0);
+    }
+    p.units = h->d_units; p.nunits = h->n_units;
+    if (p.nunits > 0) {
+        const dim3 grid((unsigned)((p.nunits + 3) / 4));
+        if (emit) hipLaunchKernelGGL((k_march3<true, FD>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_march3<false, FD>), grid, dim3(256), 0, st, p);
+    }
+    HIP_TRY(hipGetLastError());
+    h->cur = 1 - h->cur;
+    h->steps_done += 3;
+    h->passes += 1;
+    h->seams_valid = true;
+    if (h->nranks > 1) h->ghost_valid -= 3;      // three columns of ghost validity consumed
+    return WT_OK;
+}
+
+// steps one fused pass advances (0: no plan)
+static inline int fuse_stride(const wt_handle *h) { return h->fuse_ready ? h->march_depth : 0; }
+// a fused pass is possible now: plan ready and (slabs) as many exact ghost columns left as the pass consumes
+static inline bool can_fuse(const wt_handle *h) { return h->fuse_ready && (h->nranks == 1 || h->ghost_valid >= h->march_depth); }
+
+static int step_fused(wt_handle *h, double tau, double u0, bool emit)
+{
+    if (h->march_depth == 3) {
+        bool fd = false;
+        WT_TRY(fastdiv_for(h, (float)tau, &fd));
+        return fd ? step_triple_fused_t<1>(h, tau, u0, emit) : step_triple_fused_t<0>(h, tau, u0, emit);
+    }
+    return step_pair_fused(h, tau, u0, emit);
+}
 
 static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
 {
     int s = 0;
     while (s < nsteps) {
-        if (nsteps - s >= 2 && can_pair(h)) {
-            WT_TRY(step_pair_fused(h, tau, u0, s + 2 == nsteps));
-            s += 2;
+        const int k = fuse_stride(h);
+        if (k > 0 && nsteps - s >= k && can_fuse(h)) {
+            WT_TRY(step_fused(h, tau, u0, s + k == nsteps));
+            s += k;
         } else {
             WT_TRY(step_once(h, tau, u0, s + 1 == nsteps));
             s += 1;
@@ -934,14 +1034,15 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
     }
     int s = 0;
     while (s < nsteps) {
-        bool pair = nsteps - s >= 2;
-        for (int r = 0; r < n && pair; r++) pair = can_pair(hs[r]);
-        if (pair) {                                   // two steps per pass on every slab; no exchange involved
+        const int k = fuse_stride(hs[0]);
+        bool fused = k > 0 && nsteps - s >= k;
+        for (int r = 0; r < n && fused; r++) fused = fuse_stride(hs[r]) == k && can_fuse(hs[r]);
+        if (fused) {                                  // k steps per pass on every slab; no exchange involved
             for (int r = 0; r < n; r++) {
                 HIP_TRY(hipSetDevice(hs[r]->device));
-                WT_TRY(step_pair_fused(hs[r], tau, u0, s + 2 == nsteps));
+                WT_TRY(step_fused(hs[r], tau, u0, s + k == nsteps));
             }
-            s += 2;
+            s += k;
             continue;
         }
         const bool emit = (s == nsteps - 1);

@@ -69,6 +69,7 @@ def parse_args():
                          "default (on where it pays), 0 off, 1 where it pays, 2 always")
     ap.add_argument("--fuse-chunk", type=int, default=0, help="cost limit of a marching unit in columns (0 = whole resident rounds)")
     ap.add_argument("--fuse-sites", type=int, default=0, choices=[0, 2, 4], help="sites per lane of the marching kernel (0 = automatic)")
+    ap.add_argument("--fuse-depth", type=int, default=0, choices=[0, 2, 3], help="steps per pass of the marching kernel (0 = automatic)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -223,6 +224,8 @@ def main():
             eng.set_option("fuse_chunk", args.fuse_chunk)
         if args.fuse_sites > 0:
             eng.set_option("fuse_sites", args.fuse_sites)
+        if args.fuse_depth > 0 and args.dtype == "float32":
+            eng.set_option("fuse_depth", args.fuse_depth)
         if args.fuse >= 0:
             eng.set_option("fuse_steps", args.fuse)
         if distributed:
@@ -271,12 +274,18 @@ def main():
     mlups = sites * args.steps / wall / 1e6
     bpl = BYTES_PER_LUP[args.dtype]
     fused = bool(eng.get_option("fuse_active"))
-    steps_per_launch = 2 if fused else 1
-    launch_ms = dev_ms / args.steps * steps_per_launch     # one launch = one pass of the dominant kernel over the slab
+    steps_per_launch = int(eng.get_option("fuse_depth")) if fused else 1
+    # one launch = one pass of the dominant kernel over the slab (when --steps is not a multiple of the steps per pass the
+    # last one or two steps are single steps; they are averaged in)
+    launch_ms = dev_ms / args.steps * steps_per_launch
     sites_per_launch = eng.width * ny if not distributed else (nx_total // world) * ny
     key = f"{nx_total}x{ny}_{args.dtype}"
-    main_kernel = ("wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)" if fused else "wt::k_step")
-    traffic = None if distributed else measured_traffic(key + ("_march" if fused else ""))
+    main_kernel = "wt::k_step"
+    if fused and steps_per_launch == 3:
+        main_kernel = "wt::k_march3 (THREE steps per pass, body / inlet / outlet inside; + wt::k_halo3_level1/2 per pass)"
+    elif fused:
+        main_kernel = "wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)"
+    traffic = None if distributed else measured_traffic(key + (("_march3" if steps_per_launch == 3 else "_march") if fused else ""))
     r = roofline_entry(main_kernel, bpl * sites_per_launch * steps_per_launch, launch_ms, traffic)
     # `achieved` is the REAL HBM rate (counters) when this workload has been profiled, else the effective rate
     basis = "counters" if r["counter_gbps"] is not None else "effective"
@@ -284,13 +293,14 @@ def main():
     cfg_fuse = {"fuse_steps": int(fused), "fuse_chunk": int(eng.get_option("fuse_chunk")) if fused else 0,
                 "fuse_units": int(eng.get_option("fuse_units")) if fused else 0,
                 "fuse_sites": int(eng.get_option("fuse_sites")) if fused else 0,
+                "fuse_depth": steps_per_launch if fused else 0,
                 "fast_div": int(eng.get_option("fast_div_active")) if fused else 0}
     roofline = {"bound": "hbm", "kernel": main_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "achieved_basis": ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/pmc_traffic.json) / this run's launch time"
                                    if basis == "counters" else
                                    f"effective: {bpl} B per site update x sites x steps per launch / launch time"
-                                   + (" (a two-step pass moves fewer bytes than that; no counter entry for this workload)" if fused else "")),
+                                   + (" (a multi-step pass moves fewer bytes than that; no counter entry for this workload)" if fused else "")),
                 "traffic": r["traffic"], "traffic_source": r["traffic_source"], "counter_gbps": r["counter_gbps"],
                 "effective_gbps": r["effective_gbps"], "effective_frac": r["effective_frac"],
                 "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "launch_ms": launch_ms,

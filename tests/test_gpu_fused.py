@@ -12,7 +12,10 @@ from conftest import bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None, sites=0, dtype="float32"):
+COMBOS = (("float32", 4, 2), ("float32", 2, 2), ("float32", 2, 3), ("float64", 2, 2))     # dtype, sites per lane, steps per pass
+
+
+def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None, sites=0, dtype="float32", depth=2):
     ny, nx = mask.shape
     with pkg.Engine(nx, ny, dtype=dtype) as e:
         e.set_option("fuse_steps", 0)
@@ -21,11 +24,13 @@ def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None, sites=0, dtype="float32")
                 e.set_option("fuse_chunk", chunk)
             if sites:
                 e.set_option("fuse_sites", sites)
+            e.set_option("fuse_depth", depth)
             e.set_option("fuse_steps", 2)
         e.set_mask(mask)
         e.init_equilibrium(u0)
         if fuse:
             assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_units") > 0
+            assert e.get_option("fuse_depth") == depth
             if sites:
                 assert e.get_option("fuse_sites") == sites
         for n in chunks:
@@ -50,12 +55,15 @@ def _body(pkg, nx, ny, shape="naca2412", aoa=7.0):
 ])
 def test_fused_equals_single_step(pkg, nx, ny, chunks, chunk):
     mask = _body(pkg, nx, ny)
-    for dtype, sites in (("float32", 4), ("float32", 2), ("float64", 2)):
-        f0, m0, n0 = _run(pkg, mask, chunks, 0.58, 0.06, False, dtype=dtype)
-        f1, m1, n1 = _run(pkg, mask, chunks, 0.58, 0.06, True, chunk, sites, dtype)
+    ref = {}
+    for dtype, sites, depth in COMBOS:
+        if dtype not in ref:
+            ref[dtype] = _run(pkg, mask, chunks, 0.58, 0.06, False, dtype=dtype)
+        f0, m0, n0 = ref[dtype]
+        f1, m1, n1 = _run(pkg, mask, chunks, 0.58, 0.06, True, chunk, sites, dtype, depth)
         assert n0 == n1 == sum(chunks)
-        assert bits_equal(f0, f1), (dtype, sites)
-        assert all(bits_equal(a, b) for a, b in zip(m0, m1)), (dtype, sites)
+        assert bits_equal(f0, f1), (dtype, sites, depth)
+        assert all(bits_equal(a, b) for a, b in zip(m0, m1)), (dtype, sites, depth)
 
 
 def test_fused_vs_oracle_and_edge_masks(pkg, oracle_c):
@@ -66,10 +74,13 @@ def test_fused_vs_oracle_and_edge_masks(pkg, oracle_c):
     edges = np.zeros((ny, nx), np.uint8); edges[0, 10:20] = 1; edges[ny - 1, 30:40] = 1; edges[50:60, 0] = 1; edges[70:90, nx - 1] = 1; edges[100:140, 2] = 1
     specks[127:129, 400:410] = 1; specks[383:386, 450] = 1          # across the seams of 128-row windows too
     for mask in (empty, wall, specks, edges, _body(pkg, nx, ny, "naca4412", 15.0)):
-        for dtype, sites in ((np.float32, 4), (np.float32, 2), (np.float64, 2)):
-            f, m, _ = _run(pkg, mask, [8, 9], 0.58, 0.06, True, 12, sites, np.dtype(dtype).name)
-            fr, mr = oracle_c.run(mask, 17, 0.58, 0.06, dtype)
-            assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr)), (dtype, sites)
+        ref = {}
+        for dtype, sites, depth in COMBOS:
+            if dtype not in ref:
+                ref[dtype] = oracle_c.run(mask, 17, 0.58, 0.06, np.dtype(dtype))
+            fr, mr = ref[dtype]
+            f, m, _ = _run(pkg, mask, [8, 9], 0.58, 0.06, True, 12, sites, dtype, depth)
+            assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr)), (dtype, sites, depth)
 
 
 def test_fused_low_tau_clamp_and_mask_change(pkg, oracle_c):
@@ -77,15 +88,16 @@ def test_fused_low_tau_clamp_and_mask_change(pkg, oracle_c):
     m1, m2 = _body(pkg, nx, ny, "naca4412", 20.0), _body(pkg, nx, ny, "naca4412", 5.0)
     fr, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float32)
     fr, mr = oracle_c.run(m2, 100, 0.5004, 0.09, np.float32, f=fr)
-    for sites in (4, 2):
+    for sites, depth in ((4, 2), (2, 2), (2, 3)):
         with pkg.Engine(nx, ny) as e:
             e.set_option("fuse_sites", sites)
+            e.set_option("fuse_depth", depth)
             e.set_option("fuse_steps", 2)
             e.set_mask(m1); e.init_equilibrium(0.10); e.step(300, 0.5004, 0.10)
             e.set_mask(m2); e.step(100, 0.5004, 0.09)
             f, m = e.read_f(), e.read_macro()
             events = e.clamp_events()
-        assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr)), sites
+        assert bits_equal(f, fr) and all(bits_equal(a, b) for a, b in zip(m, mr)), (sites, depth)
     fr64, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float64)
     fr64, mr64 = oracle_c.run(m2, 100, 0.5004, 0.09, np.float64, f=fr64)
     with pkg.Engine(nx, ny, dtype="float64") as e:
@@ -175,17 +187,21 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
         assert float(np.hypot(ux, uy).max()) <= 0.35 * (1 + 1e-6)          # html:344-350 clamp bounds
 
 
-@pytest.mark.parametrize("nranks,halo,nx,ny,chunks,dtype,sites", [
-    (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 4),
-    (3, 7, 768, 512, [40], "float32", 4),
-    (4, 16, 2048, 512, [33, 18], "float32", 4),
-    (2, 1, 512, 256, [9], "float32", 4),              # halo 1: never two exact ghost columns -> single steps only
-    (8, 16, 4096, 256, [50], "float32", 4),
-    (4, 16, 2048, 512, [33, 18], "float32", 2),
-    (3, 7, 768, 512, [40], "float64", 2),
-    (8, 16, 4096, 256, [50], "float32", 0),           # automatic choice
+@pytest.mark.parametrize("nranks,halo,nx,ny,chunks,dtype,sites,depth", [
+    (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 4, 2),
+    (3, 7, 768, 512, [40], "float32", 4, 2),
+    (4, 16, 2048, 512, [33, 18], "float32", 4, 2),
+    (2, 1, 512, 256, [9], "float32", 4, 2),              # halo 1: never two exact ghost columns -> single steps only
+    (8, 16, 4096, 256, [50], "float32", 4, 2),
+    (4, 16, 2048, 512, [33, 18], "float32", 2, 2),
+    (3, 7, 768, 512, [40], "float64", 2, 2),
+    (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 2, 3),
+    (3, 7, 768, 512, [40], "float32", 2, 3),
+    (4, 17, 2048, 512, [33, 18], "float32", 2, 3),
+    (2, 2, 512, 256, [9], "float32", 2, 3),              # halo 2: never three exact ghost columns -> single steps only
+    (8, 16, 4096, 256, [50], "float32", 0, 0),           # automatic choice
 ])
-def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks, dtype, sites):
+def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks, dtype, sites, depth):
     """Two-steps-per-launch on column slabs (in-process transport): a pair needs two exact ghost
     columns, refresh steps stay single; results equal the plain single lattice bit for bit."""
     mask = _body(pkg, nx, ny, "naca2412", 7.0)
@@ -196,9 +212,12 @@ def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks, dty
         for e in es:
             if sites:
                 e.set_option("fuse_sites", sites)
+            if depth:
+                e.set_option("fuse_depth", depth)
             e.set_option("fuse_steps", 2)
             e.set_mask(mask); e.init_equilibrium(0.06)
         assert any(e.get_option("fuse_active") == 1.0 for e in es)
+        assert not depth or all(e.get_option("fuse_depth") == depth for e in es)
         for n in chunks:
             pkg.Engine.step_group(es, n, 0.58, 0.06)
         f1 = np.concatenate([e.read_f() for e in es], axis=2)
@@ -226,7 +245,9 @@ def test_fuse_auto_only_where_it_pays(pkg):
         for e in (wide, slab, f64):
             e.set_mask(np.zeros((e.ny, e.nx_global), np.uint8)); e.init_equilibrium(0.06)
             assert e.get_option("fuse_active") == 1.0     # the default
-        assert (wide.get_option("fuse_sites"), slab.get_option("fuse_sites"), f64.get_option("fuse_sites")) == (4, 2, 2)
+        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(3, 2), (3, 2), (2, 2)]
+        wide.set_option("fuse_depth", 2); slab.set_option("fuse_depth", 2)
+        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab)] == [(2, 4), (2, 2)]
 
 
 def test_set_mask_stays_interactive(pkg):

@@ -38,18 +38,19 @@ def test_random_case(pkg, oracle_c, seed):
     steps = [int(v) for v in rng.integers(1, 14, size=3)]
     mask = _random_mask(rng, nx, ny)
     ref_f, ref_m = oracle_c.run(mask, sum(steps), tau, u0, np.dtype(dtype))
-    for fuse in (0, 4, 2):                            # single steps; marching kernel with 4 / 2 sites per lane
+    for fuse, depth in ((0, 0), (4, 2), (2, 2), (2, 3)):     # single steps; marching kernel: sites per lane, steps per pass
         with pkg.Engine(nx, ny, dtype=dtype) as e:
             e.set_option("fuse_steps", 0)
             if fuse:
-                if ny % fuse or nx < 8 or (dtype == "float64" and fuse == 4):
+                if ny % fuse or nx < (16 if depth == 3 else 8) or (dtype == "float64" and (fuse == 4 or depth == 3)):
                     continue
                 e.set_option("fuse_chunk", int(rng.integers(1, 40)))
                 e.set_option("fuse_sites", fuse)
+                e.set_option("fuse_depth", depth)
                 e.set_option("fuse_steps", 2)
             e.set_mask(mask); e.init_equilibrium(u0)
             for n in steps:
                 e.step(n, tau, u0)
             f, m = e.read_f(), e.read_macro()
-        assert bits_equal(f, ref_f), (seed, fuse, nx, ny, dtype)
+        assert bits_equal(f, ref_f), (seed, fuse, depth, nx, ny, dtype)
         assert all(bits_equal(a, b) for a, b in zip(m, ref_m)), (seed, fuse)
