@@ -12,8 +12,8 @@
 //     level 2 of column x - 1  <- STEP_FS on level 1 of columns x-2, x-1, x               (march_stage)
 //     level 3 of column x - 2  <- STEP_FS on level 2 of columns x-3, x-2, x-1 -> stored   (march_stage)
 // The rows just outside the window come from two halo tables per pass: H1 (level-1 values) and H2 (level-2 values),
-// built by k_halo3_level1 / k_halo3_level2 from the seam buffer S3 the previous pass wrote (four rows on either side
-// of every seam) or, when that is stale, from the lattice.
+// built by k_halo3 from the seam buffer S3 the previous pass wrote (four rows on either side of every seam) or, when
+// that is stale, from the lattice.
 // Every site goes through the arithmetic of k_step three times: results are bit-identical to three single steps.
 #pragma once
 #include "step_march.hpp"
@@ -24,104 +24,123 @@ static constexpr int M3_S = 2;              // sites per lane
 static constexpr int M3_WIN = 64 * M3_S;    // window height
 static constexpr int M3_SREC = 80;          // S3 record: 2 halves x (9 slots x 4 rows + one pad slot) floats
 static constexpr int M3_SHALF = 40;
-static constexpr int M3_L1REC = 36;         // level-1 table: 4 rows x 9 directions per (seam, column)
 
 // ------------------------------------------------------------------------------------------------
 // once per pass: the two halo tables
 // ------------------------------------------------------------------------------------------------
-// L1T[(b * (nxl+2) + x + 1)][r4][k] = level-1 population k of site (x, 128 b - 2 + r4), r4 = 0..3, seam b = 1 .. nwin-1.
-// One thread per (seam, column, row).  Plain interior fluid sites take their nine inputs from the seam buffer
-// (record of the upstream column: rows 128 b - 4 .. 128 b + 3 of the lattice this pass reads) when it is valid;
-// everything else — and every site when it is not — goes through site_step1 on the lattice.
-template <int FD>
-__global__ __launch_bounds__(256) void k_halo3_level1(const float *__restrict__ fs, const float *__restrict__ seams3, const uint8_t *__restrict__ mask,
-                                                      const uint8_t *__restrict__ bcode, float *__restrict__ l1t, Geom g, int nwin, int use_seams,
-                                                      FastDiv fdv, float U0)
+// H1 / H2[(b * (nxl+2) + x + 1) * 8 + side * 4 + {0,1,2}], seam b = 1 .. nwin-1 between rows 128 b - 1 and 128 b:
+// side 0 = populations 2,5,6 of row 128 b - 1 (they move up into window b), side 1 = populations 4,7,8 of row 128 b (they move
+// down into window b - 1) — H1 after one step, H2 after two.
+//
+// One block = one seam x 62 columns.  Phase 1: thread (column cl = 0..63, row r4 = 0..3) computes the level-1 populations of
+// site (x0 - 1 + cl, 128 b - 2 + r4) into LDS.  Plain interior fluid sites take their nine inputs from the seam buffer S3
+// (record of the upstream column: rows 128 b - 4 .. 128 b + 3 of the lattice this pass reads) when it is valid; everything
+// else — and every site when it is not — goes through site_step1 on the lattice.  Phase 2: thread (column 1..62, side)
+// applies STEP_FS once more, every branch in the reference's order (html:283-360), to the level-1 values in LDS.
+static constexpr int H3_COLS = 62;          // output columns per block
+
+// once per mask upload: flags3[(b - 1) * nxl + x], bit r4 set <=> site (x, 128 b - 2 + r4) is plain interior fluid (not solid, no
+// solid neighbour, not on an inlet / outlet column or the first / last row) — one coalesced byte in place of eleven
+// scattered mask / bounce-code bytes per halo thread
+__global__ __launch_bounds__(256) void k_seam_flags3(const uint8_t *__restrict__ mask, const uint8_t *__restrict__ bcode, uint8_t *__restrict__ flags3,
+                                                     Geom g, int nwin)
 {
-    const long total = (long)(nwin - 1) * g.nxl * 4;
+    const long total = (long)(nwin - 1) * g.nxl;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    const int r4 = (int)(t & 3);
-    const long t1 = t >> 2;
-    const int x = (int)(t1 % g.nxl);
-    const int b = 1 + (int)(t1 / g.nxl);
-    const int j = M3_WIN * b - 2 + r4;
+    const int x = (int)(t % g.nxl);
+    const int b = 1 + (int)(t / g.nxl);
     const uint8_t *m = mask + g.pitch;
-    float o[9];
-    if (j >= g.ny) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) o[k] = 0.0f;
-    } else {
+    const int gi = x + g.gi0;
+    unsigned f = 0;
+    for (int r4 = 0; r4 < 4; r4++) {
+        const int j = M3_WIN * b - 2 + r4;
+        if (j <= 0 || j >= g.ny - 1 || gi <= 0 || gi >= g.nx_g - 1) continue;
         const long c = (long)x * g.pitch + j;
-        const int gi = x + g.gi0;
-        const bool plain = use_seams && gi > 0 && gi < g.nx_g - 1 && j > 0 && j < g.ny - 1 && m[c] == 0 && bcode[c] == 0;
-        if (plain) {
-            float a[9], rho, ux, uy;
-            const float *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const int q = 2 + r4 - ey_of(k);             // row j - ey_k relative to row 128 b - 4: 1..6
-                a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
-            }
-            collide_t<float, FD>(a, fdv, fdv.tau, o, rho, ux, uy);
-        } else {
-            site_step1<float, FD>(fs + g.pitch, m, g, x, j, fdv, fdv.tau, U0, o);
-        }
+        if (m[c] == 0 && bcode[c] == 0) f |= 1u << r4;
     }
-    float *dst = l1t + (((long)b * (g.nxl + 2) + x + 1) * 4 + r4) * 9;
-#pragma unroll
-    for (int k = 0; k < 9; k++) dst[k] = o[k];
+    flags3[t] = (uint8_t)f;
 }
 
-// H1 / H2[(b * (nxl+2) + x + 1) * 8 + side * 4 + {0,1,2}]: side 0 = populations 2,5,6 of row 128 b - 1 (they move up into window
-// b), side 1 = populations 4,7,8 of row 128 b (they move down into window b - 1) — H1 at level 1 (copied out of L1T), H2 at
-// level 2: STEP_FS once more, every branch in the reference's order (html:283-360), on the level-1 table.
 template <int FD>
-__global__ __launch_bounds__(256) void k_halo3_level2(const float *__restrict__ l1t, const uint8_t *__restrict__ mask, float *__restrict__ h1,
-                                                      float *__restrict__ h2, Geom g, int nwin, FastDiv fdv, float U0)
+__global__ __launch_bounds__(256) void k_halo3(const float *__restrict__ fs, const float *__restrict__ seams3, const uint8_t *__restrict__ mask,
+                                               const uint8_t *__restrict__ flags3, float *__restrict__ h1, float *__restrict__ h2, Geom g, int nwin,
+                                               int use_seams, FastDiv fdv, float U0)
 {
-    const long total = (long)(nwin - 1) * g.nxl * 2;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int side = (int)(t & 1);
-    const long t1 = t >> 1;
-    const int x = (int)(t1 % g.nxl);
-    const int b = 1 + (int)(t1 / g.nxl);
-    const int j = M3_WIN * b - 1 + side;
-    const int idx = 1 + side;                                   // row of L1T holding row j
+    __shared__ float l1[64][4][9 + 1];       // [column][row][direction] (+1: spreads the columns over the LDS banks)
+    const int nblk_x = (g.nxl + H3_COLS - 1) / H3_COLS;
+    const int b = 1 + (int)(blockIdx.x / nblk_x);
+    const int x0 = (int)(blockIdx.x % nblk_x) * H3_COLS;
     const uint8_t *m = mask + g.pitch;
-    const float *base = l1t + (((long)b * (g.nxl + 2) + x + 1) * 4 + idx) * 9;
-    auto get = [&](int k, int dx, int dy) { return base[((long)dx * 4 + dy) * 9 + k]; };
-    float o[9];
-    if (j >= g.ny) {
+    {   // ---- phase 1
+        const int cl = threadIdx.x >> 2, r4 = threadIdx.x & 3;
+        const int x = x0 - 1 + cl;
+        const int j = M3_WIN * b - 2 + r4;
+        float o[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = 0.0f;
-    } else {
-        const long c = (long)x * g.pitch + j;
-        const int gi = x + g.gi0;
-        if (m[c]) {                                                    // html:287-294 solid
+        if (x >= 0 && x < g.nxl && j < g.ny) {
+            const bool plain = use_seams && ((flags3[(long)(b - 1) * g.nxl + x] >> r4) & 1) != 0;
+            if (plain) {
+                float a[9], rho, ux, uy;
+                const float *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
 #pragma unroll
-            for (int k = 0; k < 9; k++) o[k] = get(opp_of(k), 0, 0);
-        } else if (gi == g.nx_g - 1) {                                 // html:301-312 outlet
-#pragma unroll
-            for (int k = 0; k < 9; k++) o[k] = get(k, -1, 0);
-        } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
-            feq_all<float>(1.0f, U0, 0.0f, o);
-        } else {                                                       // html:324-359 interior fluid
-            float fin[9], rho, ux, uy;
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
-                fin[k] = m[src] ? get(opp_of(k), 0, 0) : get(k, -ex_of(k), -ey_of(k));
+                for (int k = 0; k < 9; k++) {
+                    const int q = 2 + r4 - ey_of(k);             // row j - ey_k relative to row 128 b - 4: 1..6
+                    a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
+                }
+                collide_t<float, FD>(a, fdv, fdv.tau, o, rho, ux, uy);
+            } else {
+                site_step1<float, FD>(fs + g.pitch, m, g, x, j, fdv, fdv.tau, U0, o);
             }
-            collide_t<float, FD>(fin, fdv, fdv.tau, o, rho, ux, uy);
         }
+#pragma unroll
+        for (int k = 0; k < 9; k++) l1[cl][r4][k] = o[k];
     }
-    const long rec = ((long)b * (g.nxl + 2) + x + 1) * 8 + side * 4;
-    const float4 v1 = side ? make_float4(get(4, 0, 0), get(7, 0, 0), get(8, 0, 0), 0.0f) : make_float4(get(2, 0, 0), get(5, 0, 0), get(6, 0, 0), 0.0f);
-    const float4 v2 = side ? make_float4(o[4], o[7], o[8], 0.0f) : make_float4(o[2], o[5], o[6], 0.0f);
-    *reinterpret_cast<float4 *>(h1 + rec) = v1;
-    *reinterpret_cast<float4 *>(h2 + rec) = v2;
+    __syncthreads();
+    {   // ---- phase 2
+        const int cl = 1 + (threadIdx.x >> 1), side = threadIdx.x & 1;
+        const int x = x0 - 1 + cl;
+        if (threadIdx.x >= 2 * H3_COLS || x >= g.nxl) return;
+        const int j = M3_WIN * b - 1 + side;
+        const int idx = 1 + side;                               // row of l1 holding row j
+        auto get = [&](int k, int dx, int dy) { return l1[cl + dx][idx + dy][k]; };
+        float o[9];
+        if (j >= g.ny) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k] = 0.0f;
+        } else {
+            const long c = (long)x * g.pitch + j;
+            const int gi = x + g.gi0;
+            if ((flags3[(long)(b - 1) * g.nxl + x] >> idx) & 1) {          // plain interior fluid: html:324-359 without the mask reads
+                float fin[9], rho, ux, uy;
+#pragma unroll
+                for (int k = 0; k < 9; k++) fin[k] = get(k, -ex_of(k), -ey_of(k));
+                collide_t<float, FD>(fin, fdv, fdv.tau, o, rho, ux, uy);
+            } else if (m[c]) {                                             // html:287-294 solid
+#pragma unroll
+                for (int k = 0; k < 9; k++) o[k] = get(opp_of(k), 0, 0);
+            } else if (gi == g.nx_g - 1) {                                 // html:301-312 outlet
+#pragma unroll
+                for (int k = 0; k < 9; k++) o[k] = get(k, -1, 0);
+            } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
+                feq_all<float>(1.0f, U0, 0.0f, o);
+            } else {                                                       // html:324-359 interior fluid
+                float fin[9], rho, ux, uy;
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
+                    fin[k] = m[src] ? get(opp_of(k), 0, 0) : get(k, -ex_of(k), -ey_of(k));
+                }
+                collide_t<float, FD>(fin, fdv, fdv.tau, o, rho, ux, uy);
+            }
+        }
+        const long rec = ((long)b * (g.nxl + 2) + x + 1) * 8 + side * 4;
+        const float4 v1 = side ? make_float4(get(4, 0, 0), get(7, 0, 0), get(8, 0, 0), 0.0f) : make_float4(get(2, 0, 0), get(5, 0, 0), get(6, 0, 0), 0.0f);
+        const float4 v2 = side ? make_float4(o[4], o[7], o[8], 0.0f) : make_float4(o[2], o[5], o[6], 0.0f);
+        *reinterpret_cast<float4 *>(h1 + rec) = v1;
+        *reinterpret_cast<float4 *>(h2 + rec) = v2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,7 +330,72 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
 #undef STEP1
 }
 
-template <bool EMIT, int FD>
+// The same machinery stopped after level 2: TWO steps per pass on the tables of the three-step plan (units, classes, H1, seam
+// buffer S3), for the one or two steps a step count leaves over after its three-step passes.
+template <bool BODY, bool EMIT, int FD>
+__device__ __forceinline__ void march_unit3_d2(const MarchParams<float> &p, March3Addr &m, __amdgpu_buffer_rsrc_t rh1, unsigned hoff, int ia, int ib,
+                                               int uflags, int j0, int lane, bool far_win, unsigned long long nonfast_m, unsigned long long solid_m,
+                                               const float (&feq0)[9])
+{
+    const Geom &g = p.g;
+    const MarchAddr<float, M3_S> &a = m.a;
+#define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 2)) & 1ULL) != 0)
+#define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 2)) & 1ULL) != 0)
+#define STEP1(x, in, G) march_step1<BODY, FD, float, M3_S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+    const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
+    const int xend = ib;         // last column whose level 1 is computed
+    V3 s1m[3], s1c[9];           // level 1: populations 1,5,8 of column x-2; all nine of column x-1
+    V3 in[9], G1[9], mac[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) s1c[k] = mv_splat<float, M3_S>(feq0[k]);
+    s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+    if (!BODY || ia - 1 + g.gi0 >= 0) {
+        march_load_stream(a, ia - 1, in);
+        STEP1(ia - 1, in, s1c);
+    }
+    march_load_stream(a, ia, in);
+    int seam_col = -1;
+#pragma unroll 1
+    for (int x = ia; x <= xend; x++) {
+        V3 nxt[9];
+        march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);
+        const bool has1 = x - 1 >= ia;                                         // column x-1 is an output column
+        const int c1 = x - 1;
+        const float hv1 = halo_load<float>(rh1, hoff, (unsigned)(c1 > 0 ? c1 : 0) * 32u);
+        const Seam3 sp = seam3_fetch(m);
+        STEP1(x, in, G1);
+        V3 out[9];
+        march_stage<BODY, EMIT, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, out, mac);
+        march3_store<EMIT>(m, has1 ? a.voff_st : p.lat_bytes, has1 ? c1 : 0, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = has1 ? c1 : seam_col;
+        if (BODY && outlet && x == xend) break;
+        s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { s1c[k] = G1[k]; in[k] = nxt[k]; }
+    }
+    if (BODY && outlet) {
+        // x = ib = NX-1: s1c = level 1 of NX-2, G1 = level 1 of NX-1; level 2 of the outlet column = level 1 of NX-2 (html:301-312)
+        const int co = ib;
+        uint32_t solid4 = 0;
+        if (NONFAST(co)) solid4 = load_site_bytes<M3_S>(p.mask + (long)(co + 1) * g.pitch + j0);
+        V3 out[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = s1c[k];
+        if (EMIT) march_outlet_macro(s1c, mac);
+        if (__ballot(solid4 != 0) != 0ULL) { auto own1 = [&](int k) { return G1[k]; }; march_solid<float, M3_S, EMIT>(out, mac, solid4, own1); }
+        const Seam3 sp = seam3_fetch(m);
+        march3_store<EMIT>(m, a.voff_st, co, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = co;
+    }
+    seam3_flush(m, seam_col, seam3_fetch(m));
+#undef NONFAST
+#undef ALLSOLID
+#undef STEP1
+}
+
+template <int DEPTH, bool EMIT, int FD>
 __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<float> p)
 {
     const Geom &g = p.g;
@@ -373,8 +457,13 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<float> p)
         solid_m = __ballot(cls == WC_SOLID);
     }
     const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= 3 && ib + g.gi0 <= g.nx_g - 3 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
-    if (lean) march_unit3<false, EMIT, FD>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
-    else march_unit3<true, EMIT, FD>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+    if (DEPTH == 3) {
+        if (lean) march_unit3<false, EMIT, FD>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit3<true, EMIT, FD>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+    } else {
+        if (lean) march_unit3_d2<false, EMIT, FD>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit3_d2<true, EMIT, FD>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+    }
 }
 
 // Marched column range of a three-step pass: global edges as in march_range; a local slab edge loses THREE columns of

@@ -98,7 +98,6 @@ struct wt_handle {
     int fuse_depth = 0;                  // option: steps per pass (0 = automatic; 2 or 3)
     int march_depth = 0;                 // steps per pass in use (3: step_march3.hpp, fp32 with 2 sites per lane)
     void *halo2 = nullptr;               // depth 3: level-2 halo table
-    float *l1t = nullptr;                // depth 3: level-1 values of the four rows around every seam
     long long passes = 0;
     long long march_table_bytes = 0;     // wcls + halo_tab + seams + seam_plain (part of device_bytes)
     int march_s = 0;                     // sites per lane in use (4: fp32 256-row windows; 2: fp64, or fp32 on narrow lattices)
@@ -330,7 +329,6 @@ static void free_march_tables(wt_handle *h)
     if (h->seams) { (void)hipFree(h->seams); h->seams = nullptr; }
     if (h->seam_plain) { (void)hipFree(h->seam_plain); h->seam_plain = nullptr; }
     if (h->halo2) { (void)hipFree(h->halo2); h->halo2 = nullptr; }
-    if (h->l1t) { (void)hipFree(h->l1t); h->l1t = nullptr; }
     h->seams_valid = false;
     h->n_win = 0;
     h->device_bytes -= h->march_table_bytes;
@@ -364,12 +362,10 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     }
     if (!h->seam_plain && nwin > 1) { HIP_TRY(hipMalloc((void **)&h->seam_plain, (size_t)(nwin - 1) * g.nxl)); added += (long long)(nwin - 1) * g.nxl; }
     if (depth == 3 && !h->halo2) {
-        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb, lbytes = (size_t)(nwin + 1) * (g.nxl + 2) * M3_L1REC * sizeof(float);
+        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb;
         HIP_TRY(hipMalloc(&h->halo2, hbytes));
         HIP_TRY(hipMemsetAsync(h->halo2, 0, hbytes, h->s_compute));
-        HIP_TRY(hipMalloc((void **)&h->l1t, lbytes));
-        HIP_TRY(hipMemsetAsync(h->l1t, 0, lbytes, h->s_compute));
-        added += (long long)(hbytes + lbytes);
+        added += (long long)hbytes;
     }
     h->march_table_bytes += added;
     h->device_bytes += added;
@@ -387,8 +383,12 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->bcode, g);
     if (nwin > 1) {
         const long nth = (long)(nwin - 1) * g.nxl;
-        hipLaunchKernelGGL(k_seam_flags, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
-                           h->seam_plain, g, nwin, win);
+        if (depth == 3)
+            hipLaunchKernelGGL(k_seam_flags3, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
+                               h->seam_plain, g, nwin);
+        else
+            hipLaunchKernelGGL(k_seam_flags, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
+                               h->seam_plain, g, nwin, win);
     }
     HIP_TRY(hipGetLastError());
     h->host_wcls.resize(wbytes);
@@ -825,9 +825,10 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     return fd ? step_pair_fused_t<float, 2, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 2, 0>(h, tau, u0, emit);
 }
 
-// Three steps in one pass (step_march3.hpp).  A = f[cur] (time t), B = f[1-cur] (receives time t+3).
+// Three steps in one pass (step_march3.hpp), or two on the same tables (depth = 2: what a step count leaves over).
+// A = f[cur] (time t), B = f[1-cur] (receives time t + depth).
 template <int FD>
-static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit)
+static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, int depth)
 {
     const Geom &g = h->g;
     MarchParams<float> p;
@@ -846,38 +847,46 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit)
     p.rev = (int)(h->passes & 1);
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
-        const long n1 = (long)(h->n_win - 1) * g.nxl * 4, n2 = (long)(h->n_win - 1) * g.nxl * 2;
-        hipLaunchKernelGGL((k_halo3_level1<FD>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, p.fs, (const float *)p.seams, (const uint8_t *)h->mask,
-                           (const uint8_t *)h->bcode, h->l1t, g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.U0);
-        hipLaunchKernelGGL((k_halo3_level2<FD>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, (const float *)h->l1t, (const uint8_t *)h->mask,
-                           reinterpret_cast<float *>(h->halo_tab), reinterpret_cast<float *>(h->halo2), g, h->n_win, p.fdv, p.U0);
+        const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H3_COLS - 1) / H3_COLS);
+        hipLaunchKernelGGL((k_halo3<FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const float *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
+                           reinterpret_cast<float *>(h->halo_tab), reinterpret_cast<float *>(h->halo2), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.U0);
     }
     p.units = h->d_units; p.nunits = h->n_units;
     if (p.nunits > 0) {
         const dim3 grid((unsigned)((p.nunits + 3) / 4));
-        if (emit) hipLaunchKernelGGL((k_march3<true, FD>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_march3<false, FD>), grid, dim3(256), 0, st, p);
+        if (depth == 3) {
+            if (emit) hipLaunchKernelGGL((k_march3<3, true, FD>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_march3<3, false, FD>), grid, dim3(256), 0, st, p);
+        } else {
+            if (emit) hipLaunchKernelGGL((k_march3<2, true, FD>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_march3<2, false, FD>), grid, dim3(256), 0, st, p);
+        }
     }
     HIP_TRY(hipGetLastError());
     h->cur = 1 - h->cur;
-    h->steps_done += 3;
+    h->steps_done += depth;
     h->passes += 1;
     h->seams_valid = true;
-    if (h->nranks > 1) h->ghost_valid -= 3;      // three columns of ghost validity consumed
+    if (h->nranks > 1) h->ghost_valid -= depth;  // one column of ghost validity consumed per step
     return WT_OK;
 }
 
-// steps one fused pass advances (0: no plan)
-static inline int fuse_stride(const wt_handle *h) { return h->fuse_ready ? h->march_depth : 0; }
-// a fused pass is possible now: plan ready and (slabs) as many exact ghost columns left as the pass consumes
-static inline bool can_fuse(const wt_handle *h) { return h->fuse_ready && (h->nranks == 1 || h->ghost_valid >= h->march_depth); }
+// steps the next fused pass can advance given `left` steps to go (0: none — take a single step).  A pass needs as many exact
+// ghost columns as it advances steps; the three-step plan also runs two-step passes on its tables.
+static inline int fuse_stride(const wt_handle *h, int left)
+{
+    if (!h->fuse_ready) return 0;
+    const int avail = h->nranks == 1 ? left : (left < h->ghost_valid ? left : h->ghost_valid);
+    if (h->march_depth == 3) return avail >= 3 ? 3 : (avail >= 2 ? 2 : 0);
+    return avail >= 2 ? 2 : 0;
+}
 
-static int step_fused(wt_handle *h, double tau, double u0, bool emit)
+static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
 {
     if (h->march_depth == 3) {
         bool fd = false;
         WT_TRY(fastdiv_for(h, (float)tau, &fd));
-        return fd ? step_triple_fused_t<1>(h, tau, u0, emit) : step_triple_fused_t<0>(h, tau, u0, emit);
+        return fd ? step_triple_fused_t<1>(h, tau, u0, emit, k) : step_triple_fused_t<0>(h, tau, u0, emit, k);
     }
     return step_pair_fused(h, tau, u0, emit);
 }
@@ -886,9 +895,9 @@ static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
 {
     int s = 0;
     while (s < nsteps) {
-        const int k = fuse_stride(h);
-        if (k > 0 && nsteps - s >= k && can_fuse(h)) {
-            WT_TRY(step_fused(h, tau, u0, s + k == nsteps));
+        const int k = fuse_stride(h, nsteps - s);
+        if (k > 0) {
+            WT_TRY(step_fused(h, tau, u0, s + k == nsteps, k));
             s += k;
         } else {
             WT_TRY(step_once(h, tau, u0, s + 1 == nsteps));
@@ -1034,13 +1043,13 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
     }
     int s = 0;
     while (s < nsteps) {
-        const int k = fuse_stride(hs[0]);
-        bool fused = k > 0 && nsteps - s >= k;
-        for (int r = 0; r < n && fused; r++) fused = fuse_stride(hs[r]) == k && can_fuse(hs[r]);
+        const int k = fuse_stride(hs[0], nsteps - s);
+        bool fused = k > 0;
+        for (int r = 0; r < n && fused; r++) fused = fuse_stride(hs[r], nsteps - s) == k;
         if (fused) {                                  // k steps per pass on every slab; no exchange involved
             for (int r = 0; r < n; r++) {
                 HIP_TRY(hipSetDevice(hs[r]->device));
-                WT_TRY(step_fused(hs[r], tau, u0, s + k == nsteps));
+                WT_TRY(step_fused(hs[r], tau, u0, s + k == nsteps, k));
             }
             s += k;
             continue;
