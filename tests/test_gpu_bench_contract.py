@@ -41,8 +41,11 @@ def test_bench_json_contract():
 
 
 def test_bench_fused_flag_and_fp64():
-    d = _run("--fuse", "2", "--dtype", "float32")
-    assert d["config"]["fuse_steps"] == 1 and d["roofline"]["algorithmic_bytes_per_launch"] == 2 * 72 * 1024 * 512
+    d = _run("--fuse", "2", "--dtype", "float32")           # forced on a small lattice: three steps per pass (the fp32 default)
+    assert d["config"]["fuse_steps"] == 1 and d["config"]["fuse_depth"] == 3 and d["roofline"]["steps_per_launch"] == 3
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 3 * 72 * 1024 * 512
+    d = _run("--fuse", "2", "--fuse-depth", "2", "--dtype", "float32")
+    assert d["config"]["fuse_depth"] == 2 and d["roofline"]["algorithmic_bytes_per_launch"] == 2 * 72 * 1024 * 512
     d = _run("--fuse", "0")
     assert d["config"]["fuse_steps"] == 0 and d["roofline"]["algorithmic_bytes_per_launch"] == 72 * 1024 * 512
     d = _run("--dtype", "float64")
