@@ -299,12 +299,21 @@ template <typename T, int S> __device__ __forceinline__ MV<T, S> mv_splat(T x)
     return r;
 }
 
+// the value held by lane - 1 / lane + 1 as ONE data-parallel-primitive move each (v_mov_b32_dpp wave_shr:1 / wave_shl:1; lane 0 /
+// lane 63 keep their own value) — __shfl_up / __shfl_down compile to ds_bpermute_b32, an LDS round trip with a wait behind it
+__device__ __forceinline__ int dpp_wave_up(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_wave_down(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float wave_up(float x) { return __int_as_float(dpp_wave_up(__float_as_int(x))); }
+__device__ __forceinline__ float wave_down(float x) { return __int_as_float(dpp_wave_down(__float_as_int(x))); }
+__device__ __forceinline__ double wave_up(double x) { return __hiloint2double(dpp_wave_up(__double2hiint(x)), dpp_wave_up(__double2loint(x))); }
+__device__ __forceinline__ double wave_down(double x) { return __hiloint2double(dpp_wave_down(__double2hiint(x)), dpp_wave_down(__double2loint(x))); }
+
 // value at j-1 / j+1 taken from the neighbouring lane
 // (lane 0 / lane 63 take the value of the row outside the window from the halo table: `edge`, wave-uniform)
 template <typename T, int S> __device__ __forceinline__ MV<T, S> m_below(const MV<T, S> &r, int lane, T edge)
 {
     MV<T, S> o;
-    const T n = lane_up(r.v[S - 1]);
+    const T n = wave_up(r.v[S - 1]);
     o.v[0] = lane == 0 ? edge : n;
 #pragma unroll
     for (int v = 1; v < S; v++) o.v[v] = r.v[v - 1];
@@ -313,7 +322,7 @@ template <typename T, int S> __device__ __forceinline__ MV<T, S> m_below(const M
 template <typename T, int S> __device__ __forceinline__ MV<T, S> m_above(const MV<T, S> &r, int lane, T edge)
 {
     MV<T, S> o;
-    const T n = lane_down(r.v[0]);
+    const T n = wave_down(r.v[0]);
 #pragma unroll
     for (int v = 0; v < S - 1; v++) o.v[v] = r.v[v + 1];
     o.v[S - 1] = lane == 63 ? edge : n;

@@ -216,6 +216,26 @@ __device__ __forceinline__ void march3_store(const March3Addr &m, unsigned voff_
 #pragma unroll
     for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(m.lds_w + 4 * k) = make_float2(out[k].v[0], out[k].v[1]);
 }
+// Make the wait for the prefetched column land HERE (an empty asm that reads its 18 registers), before this iteration's
+// stores are issued.  Left to itself hipcc waits for them at the top of the next iteration with vmcnt(0) — the loop-entry path
+// has nothing younger in flight, and the merged counter state keeps that — which also waits for the eleven stores just
+// issued: every iteration then ends by draining its own stores.
+__device__ __forceinline__ void wait_for_column(const V3 (&c)[9], float h1 = 0.0f, float h2 = 0.0f)
+{
+#ifdef WT_M3_NOWAIT          // experiments: leave the waits to hipcc
+    return;
+#endif
+    asm volatile("" ::"v"(c[0].v[0]), "v"(c[0].v[1]), "v"(c[1].v[0]), "v"(c[1].v[1]), "v"(c[2].v[0]), "v"(c[2].v[1]), "v"(c[3].v[0]), "v"(c[3].v[1]),
+                 "v"(c[4].v[0]), "v"(c[4].v[1]), "v"(c[5].v[0]), "v"(c[5].v[1]), "v"(c[6].v[0]), "v"(c[6].v[1]), "v"(c[7].v[0]), "v"(c[7].v[1]),
+                 "v"(c[8].v[0]), "v"(c[8].v[1]), "v"(h1), "v"(h2));
+}
+// ... and keep it from drifting upwards: an asm that reads the column about to be stored is ordered before the one above
+__device__ __forceinline__ void pin_after(const V3 (&c)[9])
+{
+    asm volatile("" ::"v"(c[0].v[0]), "v"(c[0].v[1]), "v"(c[1].v[0]), "v"(c[1].v[1]), "v"(c[2].v[0]), "v"(c[2].v[1]), "v"(c[3].v[0]), "v"(c[3].v[1]),
+                 "v"(c[4].v[0]), "v"(c[4].v[1]), "v"(c[5].v[0]), "v"(c[5].v[1]), "v"(c[6].v[0]), "v"(c[6].v[1]), "v"(c[7].v[0]), "v"(c[7].v[1]),
+                 "v"(c[8].v[0]), "v"(c[8].v[1]));
+}
 struct Seam3 { float4 below, above; };
 __device__ __forceinline__ Seam3 seam3_fetch(const March3Addr &m)
 {
@@ -266,6 +286,10 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
         STEP1(ia - 1, in, s1c);
     }
     march_load_stream(a, ia, in);
+    // halo-table words of the columns the first iteration produces (fetched one iteration ahead, like the populations)
+    float hv1 = halo_load<float>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * 32u);
+    float hv2 = halo_load<float>(rh2, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * 32u);
+    wait_for_column(in, hv1, hv2);      // no load pending at the loop header: see wait_for_column
     int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
     // The loop body has no branch on the pipeline fill: during the first two iterations (x - 2 < ia) level 3 is computed on
     // don't-care values and its stores are dropped by an out-of-range offset — a scalar `if` around the stage and its
@@ -276,14 +300,17 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
         march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);               // prefetch (last one: harmless re-load)
         const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
         const int c1 = x - 1, c2 = x - 2;
-        const float hv1 = halo_load<float>(rh1, hoff, (unsigned)(c1 > 0 ? c1 : 0) * 32u);
-        const float hv2 = halo_load<float>(rh2, hoff, (unsigned)(c2 > 0 ? c2 : 0) * 32u);
+        const float hv1n = halo_load<float>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * 32u);
+        const float hv2n = halo_load<float>(rh2, hoff, (unsigned)(c2 + 1 > 0 ? c2 + 1 : 0) * 32u);
         const Seam3 sp = seam3_fetch(m);                                       // staged by the previous iteration's store
         STEP1(x, in, G1);                                                      // level 1 of column x
         // level 2 of column x-1 (a column left of the inlet takes the inlet branch: constants, no memory access)
         march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac);
         V3 out[9];
         march_stage<BODY, EMIT, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, out, mac);
+        pin_after(out);
+        wait_for_column(nxt, hv1n, hv2n);
+        hv1 = hv1n; hv2 = hv2n;
         march3_store<EMIT>(m, has2 ? a.voff_st : p.lat_bytes, has2 ? c2 : 0, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = has2 ? c2 : seam_col;
@@ -308,9 +335,9 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
         // level 3 of column NX-2
         V3 t2m[3];
         t2m[0] = s2c[1]; t2m[1] = s2c[5]; t2m[2] = s2c[8];
-        const float hv2 = halo_load<float>(rh2, hoff, (unsigned)(co - 1) * 32u);
+        const float hv2t = halo_load<float>(rh2, hoff, (unsigned)(co - 1) * 32u);
         Seam3 sp = seam3_fetch(m);
-        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2, out, mac);
+        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2t, out, mac);
         march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = co - 1;
@@ -354,6 +381,8 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<float> &p, Marc
         STEP1(ia - 1, in, s1c);
     }
     march_load_stream(a, ia, in);
+    float hv1 = halo_load<float>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * 32u);
+    wait_for_column(in, hv1);
     int seam_col = -1;
 #pragma unroll 1
     for (int x = ia; x <= xend; x++) {
@@ -361,11 +390,14 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<float> &p, Marc
         march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has1 = x - 1 >= ia;                                         // column x-1 is an output column
         const int c1 = x - 1;
-        const float hv1 = halo_load<float>(rh1, hoff, (unsigned)(c1 > 0 ? c1 : 0) * 32u);
+        const float hv1n = halo_load<float>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * 32u);
         const Seam3 sp = seam3_fetch(m);
         STEP1(x, in, G1);
         V3 out[9];
         march_stage<BODY, EMIT, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, out, mac);
+        pin_after(out);
+        wait_for_column(nxt, hv1n);
+        hv1 = hv1n;
         march3_store<EMIT>(m, has1 ? a.voff_st : p.lat_bytes, has1 ? c1 : 0, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = has1 ? c1 : seam_col;
