@@ -7,7 +7,7 @@ run, one --pmc WRITE_SIZE run) into the files kept under profiles/:
     pmc_traffic.json           the entry bench.py reports as roofline.traffic (+ where and when it was measured)
 
     python tools/summarize_profile.py <tag> <key> <trace.db> <fetch.db> <write.db>
-        key, e.g. 4096x4096_float32_march  (bench.py: "<nx>x<ny>_<dtype>" + "_march" for the two-steps-per-pass kernel)
+        key, e.g. 4096x4096_float32_march3  (bench.py: "<nx>x<ny>_<dtype>" + "_march" / "_march3" for the two- / three-steps-per-pass kernel)
 
 HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) x 1024 x 2 on gfx950 (the counter tallies 128-B requests
 at 64 B for wide coalesced reads), WRITE_SIZE (KB) x 1024; the two counters do not fit one pass, hence two runs.
@@ -60,14 +60,17 @@ def main():
             w.writerow([k, len(v), sum(v), f"{sum(v) / len(v):.1f}", f"{100.0 * sum(v) / total:.2f}", min(v), max(v)])
     fe, wr = counters(fetch_db), counters(write_db)
     march = "_march" in key
+    march3 = key.endswith("_march3")
     rows = []
     fetch_kb = write_kb = 0.0
     for k in sorted(set(fe) | set(wr)):
         f = fe.get(k, {}).get("FETCH_SIZE")
         wv = wr.get(k, {}).get("WRITE_SIZE")
         rows.append([k, f, wv])
-        if march:
-            use = (k.startswith("wt::k_march<false,") or k.startswith("wt::k_halo_from_seams"))
+        if march3:
+            use = (k.startswith("wt::k_march3<3,false,") or k.startswith("wt::k_halo3<"))
+        elif march:
+            use = ((k.startswith("wt::k_march<") and ",false," in k) or k.startswith("wt::k_halo_from_seams"))
         else:
             use = k.startswith("wt::k_step<") and ",false," in k
         if use:
@@ -84,7 +87,8 @@ def main():
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[key] = {
         "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
-        "kernel": ("one pass = wt::k_halo_from_seams + wt::k_march<false,FD> (TWO steps)" if march else "wt::k_step<float,false,...> (non-emitting step)"),
+        "kernel": ("one pass = wt::k_halo3 + wt::k_march3<3,false,FD> (THREE steps)" if march3 else
+                   "one pass = wt::k_halo_from_seams + wt::k_march<T,S,false,FD> (TWO steps)" if march else "wt::k_step<float,false,...> (non-emitting step)"),
         "measured": datetime.date.today().isoformat() + ", rocprofv3 --pmc on one MI355X box of the gpurun pool, `python bench.py` default workload, "
                     "separate passes for FETCH_SIZE and WRITE_SIZE (not the run that prints the bench line)",
         "source": f"profiles/{tag}_pmc_traffic.csv: FETCH_SIZE KB x1024 x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KB x1024",
