@@ -35,7 +35,7 @@ class SlabWindTunnel(WindTunnel):
     """The :class:`WindTunnel` surface for a lattice sharded over the ranks of a process group.
     Every method is collective: all ranks call it with the same arguments."""
 
-    def __init__(self, coords=None, name: str = "", *, halo: int = 17, device: Optional[int] = None, group=None,
+    def __init__(self, coords=None, name: str = "", *, halo: int = 16, device: Optional[int] = None, group=None,
                  engine_factory: Callable = _default_engine_factory, nx: int = 4096, ny: int = 2048, **kwargs):
         import torch.distributed as dist
         if not dist.is_initialized():
@@ -206,9 +206,9 @@ class _LocalSlabEngine:
 
 class LocalSlabWindTunnel(WindTunnel):
     """:class:`WindTunnel` over several GPUs driven by ONE process (no torch.distributed, no RCCL):
-    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=17, nx=8192, ny=4096)``."""
+    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=16, nx=8192, ny=4096)``."""
 
-    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: int = 17, **kwargs):
+    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: int = 16, **kwargs):
         self.devices = [int(d) for d in devices]
         self.halo = int(halo)
         if len(self.devices) < 2:

@@ -83,12 +83,14 @@ const char *wt_last_error(void);
 const char *wt_version(void);
 
 /* Tuning knobs (no counterpart in the reference).
- *   "fuse_steps" (0 / 1 = where it pays / 2 = always): advance TWO steps per pass over the lattice — a marching kernel
- *       that keeps the intermediate step in registers, body / inlet / outlet included (csrc/step_march.hpp); results are
- *       bit-identical either way.  fp32 and fp64 handles (whole lattices and slabs) with an even NY, at least 8 local
+ *   "fuse_steps" (0 / 1 = where it pays / 2 = always): advance SEVERAL steps per pass over the lattice — marching kernels
+ *       that keep the intermediate steps in registers, body / inlet / outlet included (csrc/step_march.hpp: two steps,
+ *       csrc/step_march3.hpp: three); results are bit-identical either way.  fp32 and fp64 handles (whole lattices and slabs) with an even NY, at least 8 local
  *       columns and a lattice below 4 GiB.  Default: 1 (environment WT_FUSE2=0|1|2 overrides at wt_create); handles
  *       that are not eligible, or too small for it to pay, stay on the single-step kernel.
- *   "fuse_sites" (0 = automatic / 2 / 4): sites per lane of the marching kernel = window height / 64.  fp64 handles
+ *   "fuse_depth" (0 = automatic / 2 / 3): steps per pass.  fp32 handles default to 3 (2 sites per lane; needs 16 local
+ *       columns), fp64 handles advance 2.  A step count that is not a multiple is finished with a shorter pass or single steps.
+ *   "fuse_sites" (0 = automatic / 2 / 4): sites per lane of the two-step marching kernel = window height / 64.  fp64 handles
  *       use 2; fp32 handles 4 (256-row windows) on wide lattices and 2 (128-row windows, twice the units) on narrow
  *       ones such as column slabs; 4 needs NY % 4 == 0.
  *   "fuse_chunk": cost limit of one marching unit in columns (0 = whole resident rounds of units, the default).
@@ -96,7 +98,8 @@ const char *wt_version(void);
  *       on-device check over all 2^23 significands has PROVED the sequence equal to the IEEE quotient for this tau
  *       (csrc/d2q9.hpp); 0 keeps the IEEE division everywhere.  Bit-identical either way.
  *       fp32 only (fp64 always divides in IEEE arithmetic).
- * wt_get_option also reports "fuse_active", "fuse_units", "fuse_sites" (in use), "fuse_tiles_general", "fast_div_active". */
+ * wt_get_option also reports "fuse_active", "fuse_units", "fuse_depth" / "fuse_sites" (in use), "fuse_tiles_general",
+ * "fast_div_active". */
 int wt_set_option(wt_handle *h, const char *name, double value);
 int wt_get_option(const wt_handle *h, const char *name, double *value);
 
