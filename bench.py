@@ -282,7 +282,7 @@ def main():
     key = f"{nx_total}x{ny}_{args.dtype}"
     main_kernel = "wt::k_step"
     if fused and steps_per_launch == 3:
-        main_kernel = "wt::k_march3 (THREE steps per pass, body / inlet / outlet inside; + wt::k_halo3_level1/2 per pass)"
+        main_kernel = "wt::k_march3 (THREE steps per pass, body / inlet / outlet inside; + wt::k_halo3 per pass)"
     elif fused:
         main_kernel = "wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)"
     traffic = None if distributed else measured_traffic(key + (("_march3" if steps_per_launch == 3 else "_march") if fused else ""))

@@ -141,7 +141,19 @@ def test_fused_not_available(pkg):
     with pkg.Engine(256, 128, dtype="float64") as e:
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_sites", 4)           # fp64 vectors hold two sites
+        with pytest.raises(pkg.WTError):
+            e.set_option("fuse_depth", 3)           # three levels of fp64 columns do not fit the register file
+        with pytest.raises(pkg.WTError):
+            e.set_option("fuse_depth", 4)
         e.set_option("fuse_steps", 2)
+        e.set_mask(np.zeros((128, 256), np.uint8)); e.init_equilibrium(0.06); e.step(5, 0.58, 0.06)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 2
+    with pkg.Engine(12, 64) as e:                   # fewer than 16 columns: two steps per pass at most
+        with pytest.raises(pkg.WTError):
+            e.set_option("fuse_depth", 3)
+        e.set_option("fuse_steps", 2)
+        e.set_mask(np.zeros((64, 12), np.uint8)); e.init_equilibrium(0.06); e.step(5, 0.58, 0.06)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 2
     with pkg.Engine(256, 129) as e:                 # odd NY: no vector width divides it
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_steps", 2)
