@@ -1,0 +1,63 @@
+"""One rank of the multi-GPU RCCL test (launched by tests/test_gpu_rccl_multi.py through torch.distributed.run, one process
+per GPU): the column-slab tunnel over the library's own RCCL transport against the single lattice, bit for bit."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import airfoil_cfd_tool_amd as pkg
+    nx, ny, halo = 2048, 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    chunks = [1, 2, 3, 40, 17]
+    mask = pkg.geometry.build_geometry(nx, ny, 9.0, None, "naca4412").mask
+    ok = True
+    for dtype, depth in (("float32", 0), ("float32", 2), ("float64", 0)):
+        eng = pkg.Engine(nx, ny, dtype=dtype, device=local, rank=rank, nranks=world, halo=halo)
+        if depth:
+            eng.set_option("fuse_depth", depth)
+        eng.set_option("fuse_steps", 2)
+        ids = [pkg.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init_rank(ids[0])
+        eng.set_mask(mask); eng.init_equilibrium(0.06)
+        for n in chunks:
+            eng.step(n, 0.58, 0.06)
+        f = eng.read_f()                                    # this rank's owned columns
+        rho, ux, uy = eng.read_macro()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (f, rho, ux, uy))
+        eng.close()
+        if rank == 0:
+            with pkg.Engine(nx, ny, dtype=dtype, device=local) as ref:
+                ref.set_option("fuse_steps", 0)
+                ref.set_mask(mask); ref.init_equilibrium(0.06)
+                for n in chunks:
+                    ref.step(n, 0.58, 0.06)
+                fr, (r0, u0, v0) = ref.read_f(), ref.read_macro()
+            fa = np.concatenate([g[0] for g in gathered], axis=2)
+            same = (np.array_equal(fa.view(np.uint8), fr.view(np.uint8))
+                    and all(np.array_equal(np.concatenate([g[i] for g in gathered], axis=1).view(np.uint8), m.view(np.uint8))
+                            for i, m in ((1, r0), (2, u0), (3, v0))))
+            print(f"rccl slabs {dtype} depth={depth or 'auto'} world={world}: {'PASS' if same else 'FAIL'}", flush=True)
+            ok &= bool(same)
+    flag = torch.tensor([1 if ok else 0], device=torch.device("cuda", local))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()
