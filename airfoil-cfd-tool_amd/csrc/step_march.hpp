@@ -45,6 +45,9 @@
 #include <vector>
 #include "step_fast.hpp"
 
+#ifndef WT_LOAD_AUX
+#define WT_LOAD_AUX 2       // cache policy of the streamed lattice loads: nt (read once per pass)
+#endif
 #ifndef WT_STORE_AUX
 #define WT_STORE_AUX 2      // cache policy of the lattice stores: nt (written once, read by the NEXT pass); measured 2-4.5 % faster than 0
 #endif
@@ -340,10 +343,10 @@ __device__ __forceinline__ MV<T, S> bload(__amdgpu_buffer_rsrc_t r, unsigned vof
 {
     MV<T, S> o;
     if constexpr (S * sizeof(T) == 16) {
-        const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);     // aux 2 = nt (read once per pass)
+        const u4v x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, WT_LOAD_AUX);
         __builtin_memcpy(&o, &x, 16);
     } else {
-        const u2v x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2);
+        const u2v x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, WT_LOAD_AUX);
         __builtin_memcpy(&o, &x, 8);
     }
     return o;

@@ -148,6 +148,13 @@ __global__ __launch_bounds__(256) void k_halo3(const float *__restrict__ fs, con
 // ------------------------------------------------------------------------------------------------
 typedef MV<float, M3_S> V3;
 
+#ifdef WT_M3_STAMPS          // diagnostic build (tools/m3_stamps.py): where does an iteration of the lean three-step loop spend its clocks?
+__device__ unsigned long long g_m3_stamps[8];
+#define M3_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_[i] += t_ - tprev_; tprev_ = t_; } while (0)
+#else
+#define M3_STAMP(i) do { } while (0)
+#endif
+
 struct March3Addr {
     MarchAddr<float, M3_S> a;            // lattice / macro descriptors and offsets (its seam fields are unused here)
     __amdgpu_buffer_rsrc_t rs3;          // seam buffer S3
@@ -291,6 +298,9 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
     float hv2 = halo_load<float>(rh2, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * 32u);
     wait_for_column(in, hv1, hv2);      // no load pending at the loop header: see wait_for_column
     int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
+#ifdef WT_M3_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_amdgcn_s_memtime();
+#endif
     // The loop body has no branch on the pipeline fill: during the first two iterations (x - 2 < ia) level 3 is computed on
     // don't-care values and its stores are dropped by an out-of-range offset — a scalar `if` around the stage and its
     // stores makes hipcc's waitcnt pass drain vmcnt(0) at the merge points of every iteration.
@@ -303,16 +313,28 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
         const float hv1n = halo_load<float>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * 32u);
         const float hv2n = halo_load<float>(rh2, hoff, (unsigned)(c2 + 1 > 0 ? c2 + 1 : 0) * 32u);
         const Seam3 sp = seam3_fetch(m);                                       // staged by the previous iteration's store
+        M3_STAMP(0);                                                           // issue of the prefetch
         STEP1(x, in, G1);                                                      // level 1 of column x
+        M3_STAMP(1);
         // level 2 of column x-1 (a column left of the inlet takes the inlet branch: constants, no memory access)
         march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac);
+#ifdef WT_M3_STAMPS
+        pin_after(G2);
+#endif
+        M3_STAMP(2);
         V3 out[9];
         march_stage<BODY, EMIT, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, out, mac);
         pin_after(out);
+        M3_STAMP(3);
         wait_for_column(nxt, hv1n, hv2n);
+#ifdef WT_M3_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        M3_STAMP(4);                                                           // the wait for the prefetched column
         hv1 = hv1n; hv2 = hv2n;
         march3_store<EMIT>(m, has2 ? a.voff_st : p.lat_bytes, has2 ? c2 : 0, out, mac);
         seam3_flush(m, seam_col, sp);
+        M3_STAMP(5);                                                           // issue of the stores
         seam_col = has2 ? c2 : seam_col;
         if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
         s2m[0] = s2c[1]; s2m[1] = s2c[5]; s2m[2] = s2c[8];
@@ -320,6 +342,13 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
 #pragma unroll
         for (int k = 0; k < 9; k++) { s2c[k] = G2[k]; s1c[k] = G1[k]; in[k] = nxt[k]; }
     }
+#ifdef WT_M3_STAMPS
+    if (!BODY && lane == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd(&g_m3_stamps[i], st_[i]);
+        atomicAdd(&g_m3_stamps[6], (unsigned long long)(xend - ia + 1));
+        atomicAdd(&g_m3_stamps[7], 1ULL);
+    }
+#endif
     if (BODY && outlet) {
         // Here x = ib = NX-1 (local): s1c = level 1 of NX-2, G1 = level 1 of NX-1, s2c = level 2 of NX-3, G2 = level 2 of NX-2;
         // level 3 of NX-3 is stored.  The outlet column copies the previous level of column NX-2 (html:301-312):

@@ -21,6 +21,9 @@
 #include "step_fast.hpp"
 #include "step_march.hpp"
 #include "step_march3.hpp"
+#ifndef WT_LOAD_AUX
+#define WT_LOAD_AUX 2
+#endif
 
 using namespace wt;
 
@@ -474,6 +477,16 @@ static int rebuild_fuse_plan(wt_handle *h)
     }
     return WT_OK;
 }
+
+#ifdef WT_M3_STAMPS          // diagnostic build only (tools/m3_stamps.py); not part of the ABI
+extern "C" int wt_debug_m3_stamps(unsigned long long *out, int reset)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(wt::g_m3_stamps), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(wt::g_m3_stamps), z, sizeof(z))); }
+    return WT_OK;
+}
+#endif
 
 extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
 {
