@@ -432,7 +432,8 @@ __device__ __forceinline__ void march_load_stream(const MarchAddr<T, S> &a, int 
 template <int S> __device__ __forceinline__ uint32_t load_site_bytes(const uint8_t *p)
 {
     if constexpr (S == 4) return *reinterpret_cast<const uint32_t *>(p);
-    else return *reinterpret_cast<const uint16_t *>(p);
+    else if constexpr (S == 2) return *reinterpret_cast<const uint16_t *>(p);
+    else return *p;
 }
 
 // collide S sites per lane; fp32: one wave-uniform decision between the fast and the IEEE division by tau

@@ -1,4 +1,7 @@
-// step_march3.hpp — THREE lattice steps per pass (fp32, 2 sites per lane, 128-row windows).
+// step_march3.hpp — THREE lattice steps per pass: 8-byte vectors per lane and direction —
+//   <float, 2>  fp32, 2 sites per lane, 128-row windows (the fp32 default);
+//   <double, 1> fp64, 1 site per lane, 64-row windows.
+// Below, "128 rows" stands for WIN = 64 * S.
 //
 // Why: the SQ counters of the two-step kernel (profiles/r02_c_sq_counters.txt) show its vector-memory issue stalled on a
 // full texture-addresser command FIFO for about as many cycles as the kernel runs, with the vector ALU 30 % busy — it is
@@ -20,9 +23,7 @@
 
 namespace wt {
 
-static constexpr int M3_S = 2;              // sites per lane
-static constexpr int M3_WIN = 64 * M3_S;    // window height
-static constexpr int M3_SREC = 80;          // S3 record: 2 halves x (9 slots x 4 rows + one pad slot) floats
+static constexpr int M3_SREC = 80;          // S3 record: 2 halves x (9 slots x 4 rows + one pad slot) elements
 static constexpr int M3_SHALF = 40;
 
 // ------------------------------------------------------------------------------------------------
@@ -43,7 +44,7 @@ static constexpr int H3_COLS = 62;          // output columns per block
 // solid neighbour, not on an inlet / outlet column or the first / last row) — one coalesced byte in place of eleven
 // scattered mask / bounce-code bytes per halo thread
 __global__ __launch_bounds__(256) void k_seam_flags3(const uint8_t *__restrict__ mask, const uint8_t *__restrict__ bcode, uint8_t *__restrict__ flags3,
-                                                     Geom g, int nwin)
+                                                     Geom g, int nwin, int win)
 {
     const long total = (long)(nwin - 1) * g.nxl;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void k_seam_flags3(const uint8_t *__restrict__
     const int gi = x + g.gi0;
     unsigned f = 0;
     for (int r4 = 0; r4 < 4; r4++) {
-        const int j = M3_WIN * b - 2 + r4;
+        const int j = win * b - 2 + r4;
         if (j <= 0 || j >= g.ny - 1 || gi <= 0 || gi >= g.nx_g - 1) continue;
         const long c = (long)x * g.pitch + j;
         if (m[c] == 0 && bcode[c] == 0) f |= 1u << r4;
@@ -62,12 +63,13 @@ __global__ __launch_bounds__(256) void k_seam_flags3(const uint8_t *__restrict__
     flags3[t] = (uint8_t)f;
 }
 
-template <int FD>
-__global__ __launch_bounds__(256) void k_halo3(const float *__restrict__ fs, const float *__restrict__ seams3, const uint8_t *__restrict__ mask,
-                                               const uint8_t *__restrict__ flags3, float *__restrict__ h1, float *__restrict__ h2, Geom g, int nwin,
-                                               int use_seams, FastDiv fdv, float U0)
+template <typename T, int S, int FD>
+__global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
+                                               const uint8_t *__restrict__ flags3, T *__restrict__ h1, T *__restrict__ h2, Geom g, int nwin,
+                                               int use_seams, FastDiv fdv, T tau, T U0)
 {
-    __shared__ float l1[64][4][9 + 1];       // [column][row][direction] (+1: spreads the columns over the LDS banks)
+    constexpr int M3_WIN = 64 * S;
+    __shared__ T l1[64][4][9 + 1];       // [column][row][direction] (+1: spreads the columns over the LDS banks)
     const int nblk_x = (g.nxl + H3_COLS - 1) / H3_COLS;
     const int b = 1 + (int)(blockIdx.x / nblk_x);
     const int x0 = (int)(blockIdx.x % nblk_x) * H3_COLS;
@@ -76,22 +78,22 @@ __global__ __launch_bounds__(256) void k_halo3(const float *__restrict__ fs, con
         const int cl = threadIdx.x >> 2, r4 = threadIdx.x & 3;
         const int x = x0 - 1 + cl;
         const int j = M3_WIN * b - 2 + r4;
-        float o[9];
+        T o[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) o[k] = 0.0f;
+        for (int k = 0; k < 9; k++) o[k] = T(0);
         if (x >= 0 && x < g.nxl && j < g.ny) {
             const bool plain = use_seams && ((flags3[(long)(b - 1) * g.nxl + x] >> r4) & 1) != 0;
             if (plain) {
-                float a[9], rho, ux, uy;
-                const float *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
+                T a[9], rho, ux, uy;
+                const T *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
                     const int q = 2 + r4 - ey_of(k);             // row j - ey_k relative to row 128 b - 4: 1..6
                     a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
                 }
-                collide_t<float, FD>(a, fdv, fdv.tau, o, rho, ux, uy);
+                collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
             } else {
-                site_step1<float, FD>(fs + g.pitch, m, g, x, j, fdv, fdv.tau, U0, o);
+                site_step1<T, FD>(fs + g.pitch, m, g, x, j, fdv, tau, U0, o);
             }
         }
 #pragma unroll
@@ -105,18 +107,18 @@ __global__ __launch_bounds__(256) void k_halo3(const float *__restrict__ fs, con
         const int j = M3_WIN * b - 1 + side;
         const int idx = 1 + side;                               // row of l1 holding row j
         auto get = [&](int k, int dx, int dy) { return l1[cl + dx][idx + dy][k]; };
-        float o[9];
+        T o[9];
         if (j >= g.ny) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) o[k] = 0.0f;
+            for (int k = 0; k < 9; k++) o[k] = T(0);
         } else {
             const long c = (long)x * g.pitch + j;
             const int gi = x + g.gi0;
             if ((flags3[(long)(b - 1) * g.nxl + x] >> idx) & 1) {          // plain interior fluid: html:324-359 without the mask reads
-                float fin[9], rho, ux, uy;
+                T fin[9], rho, ux, uy;
 #pragma unroll
                 for (int k = 0; k < 9; k++) fin[k] = get(k, -ex_of(k), -ey_of(k));
-                collide_t<float, FD>(fin, fdv, fdv.tau, o, rho, ux, uy);
+                collide_t<T, FD>(fin, fdv, tau, o, rho, ux, uy);
             } else if (m[c]) {                                             // html:287-294 solid
 #pragma unroll
                 for (int k = 0; k < 9; k++) o[k] = get(opp_of(k), 0, 0);
@@ -124,29 +126,29 @@ __global__ __launch_bounds__(256) void k_halo3(const float *__restrict__ fs, con
 #pragma unroll
                 for (int k = 0; k < 9; k++) o[k] = get(k, -1, 0);
             } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
-                feq_all<float>(1.0f, U0, 0.0f, o);
+                feq_all<T>(T(1), U0, T(0), o);
             } else {                                                       // html:324-359 interior fluid
-                float fin[9], rho, ux, uy;
+                T fin[9], rho, ux, uy;
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
                     const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
                     fin[k] = m[src] ? get(opp_of(k), 0, 0) : get(k, -ex_of(k), -ey_of(k));
                 }
-                collide_t<float, FD>(fin, fdv, fdv.tau, o, rho, ux, uy);
+                collide_t<T, FD>(fin, fdv, tau, o, rho, ux, uy);
             }
         }
         const long rec = ((long)b * (g.nxl + 2) + x + 1) * 8 + side * 4;
-        const float4 v1 = side ? make_float4(get(4, 0, 0), get(7, 0, 0), get(8, 0, 0), 0.0f) : make_float4(get(2, 0, 0), get(5, 0, 0), get(6, 0, 0), 0.0f);
-        const float4 v2 = side ? make_float4(o[4], o[7], o[8], 0.0f) : make_float4(o[2], o[5], o[6], 0.0f);
-        *reinterpret_cast<float4 *>(h1 + rec) = v1;
-        *reinterpret_cast<float4 *>(h2 + rec) = v2;
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        const t4 v1 = side ? t4{get(4, 0, 0), get(7, 0, 0), get(8, 0, 0), T(0)} : t4{get(2, 0, 0), get(5, 0, 0), get(6, 0, 0), T(0)};
+        const t4 v2 = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
+        *reinterpret_cast<t4 *>(h1 + rec) = v1;
+        *reinterpret_cast<t4 *>(h2 + rec) = v2;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // the marching kernel
 // ------------------------------------------------------------------------------------------------
-typedef MV<float, M3_S> V3;
 
 #ifdef WT_M3_STAMPS          // diagnostic build (tools/m3_stamps.py): where does an iteration of the lean three-step loop spend its clocks?
 __device__ unsigned long long g_m3_stamps[8];
@@ -155,22 +157,25 @@ __device__ unsigned long long g_m3_stamps[8];
 #define M3_STAMP(i) do { } while (0)
 #endif
 
+template <typename T, int S>
 struct March3Addr {
-    MarchAddr<float, M3_S> a;            // lattice / macro descriptors and offsets (its seam fields are unused here)
+    MarchAddr<T, S> a;                   // lattice / macro descriptors and offsets (its seam fields are unused here)
     __amdgpu_buffer_rsrc_t rs3;          // seam buffer S3
-    unsigned voff_lo, voff_hi;           // lanes 0..9: byte offsets of their 16-byte slot in the two half records this window writes
-    float *lds_w, *lds_r;
+    unsigned voff_lo, voff_hi;           // lanes 0 .. 10 sizeof(T)/4 - 1: byte offsets of their 16-byte chunk in the two half records this window writes
+    T *lds_w;                            // where this lane stages its S rows of direction 0 (direction k: + 4 k elements)
+    const char *lds_r;                   // this lane's 16-byte chunk of the staged `below` half (`above`: + 40 elements)
 };
 
 // one more application of STEP_FS in registers: level k+1 of column c from level k of columns c-1 (populations 1,5,8: m158),
 // c (all nine: Gc) and c+1 (3,6,7 of Gn); `hv` = this column's halo-table word (lanes 0..5)
-template <bool BODY, bool WANT_MACRO, int FD>
-__device__ __forceinline__ void march_stage(const MarchParams<float> &p, int c, int j0, int lane, bool far_win, bool nf, bool allsolid,
-                                            const float (&feq0)[9], const V3 (&m158)[3], const V3 (&Gc)[9], const V3 (&Gn)[9], float hv,
-                                            V3 (&out)[9], V3 (&mac)[3])
+template <bool BODY, bool WANT_MACRO, int FD, typename T, int S>
+__device__ __forceinline__ void march_stage(const MarchParams<T> &p, int c, int j0, int lane, bool far_win, bool nf, bool allsolid,
+                                            const T (&feq0)[9], const MV<T, S> (&m158)[3], const MV<T, S> (&Gc)[9], const MV<T, S> (&Gn)[9], T hv,
+                                            MV<T, S> (&out)[9], MV<T, S> (&mac)[3])
 {
+    typedef MV<T, S> V3;
     const Geom &g = p.g;
-    const float hb2 = readlane_t(hv, 0), hb5 = readlane_t(hv, 1), hb6 = readlane_t(hv, 2), ha4 = readlane_t(hv, 3), ha7 = readlane_t(hv, 4),
+    const T hb2 = readlane_t(hv, 0), hb5 = readlane_t(hv, 1), hb6 = readlane_t(hv, 2), ha4 = readlane_t(hv, 3), ha7 = readlane_t(hv, 4),
                 ha8 = readlane_t(hv, 5);
     V3 fin[9];
     fin[0] = Gc[0]; fin[1] = m158[0]; fin[3] = Gn[3];
@@ -182,96 +187,107 @@ __device__ __forceinline__ void march_stage(const MarchParams<float> &p, int c, 
             auto ownc = [&](int k) { return Gc[k]; };
             uint32_t solid4 = 0, code4 = 0;
             if (nf) {
-                solid4 = load_site_bytes<M3_S>(p.mask + (long)(c + 1) * g.pitch + j0);
-                code4 = load_site_bytes<M3_S>(p.bcode + (long)c * g.pitch + j0);
+                solid4 = load_site_bytes<S>(p.mask + (long)(c + 1) * g.pitch + j0);
+                code4 = load_site_bytes<S>(p.bcode + (long)c * g.pitch + j0);
             }
             const bool any_solid = __ballot(solid4 != 0) != 0ULL;
             if (gi <= 0) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) out[k] = mv_splat<float, M3_S>(feq0[k]);
-                if (WANT_MACRO) { mac[0] = mv_splat<float, M3_S>(1.0f); mac[1] = mv_splat<float, M3_S>(p.U0); mac[2] = mv_splat<float, M3_S>(0.0f); }
+                for (int k = 0; k < 9; k++) out[k] = mv_splat<T, S>(feq0[k]);
+                if (WANT_MACRO) { mac[0] = mv_splat<T, S>(T(1)); mac[1] = mv_splat<T, S>(p.U0); mac[2] = mv_splat<T, S>(T(0)); }
             } else if (allsolid) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) out[k] = Gc[k];        // every site is overwritten by march_solid below
-                if (WANT_MACRO) { mac[0] = mv_splat<float, M3_S>(1.0f); mac[1] = mv_splat<float, M3_S>(0.0f); mac[2] = mv_splat<float, M3_S>(0.0f); }
+                if (WANT_MACRO) { mac[0] = mv_splat<T, S>(T(1)); mac[1] = mv_splat<T, S>(T(0)); mac[2] = mv_splat<T, S>(T(0)); }
             } else {
-                march_bounce<float, M3_S>(fin, code4, ownc);
-                march_collide_general<float, M3_S, FD, WANT_MACRO>(fin, solid4, j0, g.ny, p.fdv, p.tau, p.U0, feq0, out, mac);
+                march_bounce<T, S>(fin, code4, ownc);
+                march_collide_general<T, S, FD, WANT_MACRO>(fin, solid4, j0, g.ny, p.fdv, p.tau, p.U0, feq0, out, mac);
             }
-            if (any_solid && (gi <= 0 || allsolid)) march_solid<float, M3_S, WANT_MACRO>(out, mac, solid4, ownc);
+            if (any_solid && (gi <= 0 || allsolid)) march_solid<T, S, WANT_MACRO>(out, mac, solid4, ownc);
             return;
         }
     }
-    march_collide<float, M3_S, FD, WANT_MACRO>(fin, p.fdv, p.tau, out, mac);
-    if (far_win) march_far_rows<float, M3_S, WANT_MACRO>(j0, g.ny, p.U0, feq0, out, mac);
+    march_collide<T, S, FD, WANT_MACRO>(fin, p.fdv, p.tau, out, mac);
+    if (far_win) march_far_rows<T, S, WANT_MACRO>(j0, g.ny, p.U0, feq0, out, mac);
 }
 
 // nine lattice stores (+ three macro stores) of column `col`, then STAGE the four rows on either side of the window's
-// seams in LDS (lanes 0,1 hold rows 0..3, lanes 62,63 rows 124..127; every lane writes — the others into a scratch area)
+// seams in LDS (the first 4/S lanes hold rows 0..3, the last 4/S lanes the last four rows; every lane writes its 8 bytes
+// — the others into a scratch area)
 // (`voff_st`: the lane's store offset, or an out-of-range one to drop the column's stores without a branch)
-template <bool EMIT>
-__device__ __forceinline__ void march3_store(const March3Addr &m, unsigned voff_st, int col, const V3 (&out)[9], const V3 (&mac)[3])
+template <bool EMIT, typename T, int S>
+__device__ __forceinline__ void march3_store(const March3Addr<T, S> &m, unsigned voff_st, int col, const MV<T, S> (&out)[9], const MV<T, S> (&mac)[3])
 {
-    const MarchAddr<float, M3_S> &a = m.a;
+    const MarchAddr<T, S> &a = m.a;
 #pragma unroll
-    for (int k = 0; k < 9; k++) (void)bstore<float, M3_S>(a.rd, voff_st, lat_off(a, k, col, 0), out[k]);
+    for (int k = 0; k < 9; k++) (void)bstore<T, S>(a.rd, voff_st, lat_off(a, k, col, 0), out[k]);
     if (EMIT) {
         const unsigned mo = (unsigned)col * a.pitch4;
 #pragma unroll
-        for (int q = 0; q < 3; q++) (void)bstore<float, M3_S>(a.rm, voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
+        for (int q = 0; q < 3; q++) (void)bstore<T, S>(a.rm, voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
     }
 #pragma unroll
-    for (int k = 0; k < 9; k++) *reinterpret_cast<float2 *>(m.lds_w + 4 * k) = make_float2(out[k].v[0], out[k].v[1]);
+    for (int k = 0; k < 9; k++) {
+        u2v x;
+        __builtin_memcpy(&x, &out[k], 8);
+        *reinterpret_cast<u2v *>(m.lds_w + 4 * k) = x;
+    }
 }
 // Make the wait for the prefetched column land HERE (an empty asm that reads its 18 registers), before this iteration's
 // stores are issued.  Left to itself hipcc waits for them at the top of the next iteration with vmcnt(0) — the loop-entry path
 // has nothing younger in flight, and the merged counter state keeps that — which also waits for the eleven stores just
 // issued: every iteration then ends by draining its own stores.
-__device__ __forceinline__ void wait_for_column(const V3 (&c)[9], float h1 = 0.0f, float h2 = 0.0f)
+template <typename T, int S>
+__device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1 = T(0), T h2 = T(0))
 {
 #ifdef WT_M3_NOWAIT          // experiments: leave the waits to hipcc
     return;
 #endif
-    asm volatile("" ::"v"(c[0].v[0]), "v"(c[0].v[1]), "v"(c[1].v[0]), "v"(c[1].v[1]), "v"(c[2].v[0]), "v"(c[2].v[1]), "v"(c[3].v[0]), "v"(c[3].v[1]),
-                 "v"(c[4].v[0]), "v"(c[4].v[1]), "v"(c[5].v[0]), "v"(c[5].v[1]), "v"(c[6].v[0]), "v"(c[6].v[1]), "v"(c[7].v[0]), "v"(c[7].v[1]),
-                 "v"(c[8].v[0]), "v"(c[8].v[1]), "v"(h1), "v"(h2));
+    u2v r[9];                // the raw 8 bytes of every vector: the same registers, whatever T and S are
+#pragma unroll
+    for (int k = 0; k < 9; k++) __builtin_memcpy(&r[k], &c[k], 8);
+    asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(r[8]), "v"(h1), "v"(h2));
 }
 // ... and keep it from drifting upwards: an asm that reads the column about to be stored is ordered before the one above
-__device__ __forceinline__ void pin_after(const V3 (&c)[9])
+template <typename T, int S>
+__device__ __forceinline__ void pin_after(const MV<T, S> (&c)[9])
 {
-    asm volatile("" ::"v"(c[0].v[0]), "v"(c[0].v[1]), "v"(c[1].v[0]), "v"(c[1].v[1]), "v"(c[2].v[0]), "v"(c[2].v[1]), "v"(c[3].v[0]), "v"(c[3].v[1]),
-                 "v"(c[4].v[0]), "v"(c[4].v[1]), "v"(c[5].v[0]), "v"(c[5].v[1]), "v"(c[6].v[0]), "v"(c[6].v[1]), "v"(c[7].v[0]), "v"(c[7].v[1]),
-                 "v"(c[8].v[0]), "v"(c[8].v[1]));
+    u2v r[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) __builtin_memcpy(&r[k], &c[k], 8);
+    asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(r[8]));
 }
-struct Seam3 { float4 below, above; };
-__device__ __forceinline__ Seam3 seam3_fetch(const March3Addr &m)
+struct Seam3 { u4v below, above; };      // one 16-byte chunk of each staged half
+template <typename T, int S>
+__device__ __forceinline__ Seam3 seam3_fetch(const March3Addr<T, S> &m)
 {
     Seam3 r;
-    r.below = *reinterpret_cast<const float4 *>(m.lds_r);                  // rows 124..127 of direction `lane`
-    r.above = *reinterpret_cast<const float4 *>(m.lds_r + M3_SHALF);       // rows 0..3
+    r.below = *reinterpret_cast<const u4v *>(m.lds_r);                                      // the window's last four rows
+    r.above = *reinterpret_cast<const u4v *>(m.lds_r + M3_SHALF * sizeof(T));              // rows 0..3
     return r;
 }
-__device__ __forceinline__ void seam3_flush(const March3Addr &m, int col, const Seam3 &r)
+template <typename T, int S>
+__device__ __forceinline__ void seam3_flush(const March3Addr<T, S> &m, int col, const Seam3 &r)
 {
-    const unsigned so = (unsigned)(col + 1) * (unsigned)(M3_SREC * 4);
-    u4v d0, d1;
-    d0.x = __float_as_uint(r.below.x); d0.y = __float_as_uint(r.below.y); d0.z = __float_as_uint(r.below.z); d0.w = __float_as_uint(r.below.w);
-    d1.x = __float_as_uint(r.above.x); d1.y = __float_as_uint(r.above.y); d1.z = __float_as_uint(r.above.z); d1.w = __float_as_uint(r.above.w);
+    const unsigned so = (unsigned)(col + 1) * (unsigned)(M3_SREC * sizeof(T));
+    const u4v d0 = r.below, d1 = r.above;
     __builtin_amdgcn_raw_buffer_store_b128(d0, m.rs3, m.voff_hi, so, 0);        // -> seam w+1, half 0
     __builtin_amdgcn_raw_buffer_store_b128(d1, m.rs3, m.voff_lo, so, 0);        // -> seam w,   half 1
     store_data_fence2(d0, d1);
 }
 
-template <bool BODY, bool EMIT, int FD>
-__device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3Addr &m, __amdgpu_buffer_rsrc_t rh1, __amdgpu_buffer_rsrc_t rh2, unsigned hoff,
+template <bool BODY, bool EMIT, int FD, typename T, int S>
+__device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, __amdgpu_buffer_rsrc_t rh2, unsigned hoff,
                                             int ia, int ib, int uflags, int j0, int lane, bool far_win, unsigned long long nonfast_m,
-                                            unsigned long long solid_m, const float (&feq0)[9])
+                                            unsigned long long solid_m, const T (&feq0)[9])
 {
+    typedef MV<T, S> V3;
+    constexpr unsigned HREC = 8 * sizeof(T);     // bytes of one halo-table record
     const Geom &g = p.g;
-    const MarchAddr<float, M3_S> &a = m.a;
+    const MarchAddr<T, S> &a = m.a;
 #define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 2)) & 1ULL) != 0)
 #define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 2)) & 1ULL) != 0)
-#define STEP1(x, in, G) march_step1<BODY, FD, float, M3_S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+#define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
     const int xend = outlet ? ib : ib + 1;       // last column whose level 1 is computed (the outlet column itself for the last unit)
     V3 s1m[3], s1c[9];           // level 1: populations 1,5,8 of column x-2; all nine of column x-1
@@ -280,7 +296,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
     // ---- prologue: level 1 of columns ia-2 and ia-1 (columns left of the inlet do not exist: the inlet column's far-field
     //      value stands in — never used, the inlet column is a constant at every level)
 #pragma unroll
-    for (int k = 0; k < 9; k++) { s1c[k] = mv_splat<float, M3_S>(feq0[k]); s2c[k] = s1c[k]; }
+    for (int k = 0; k < 9; k++) { s1c[k] = mv_splat<T, S>(feq0[k]); s2c[k] = s1c[k]; }
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     s2m[0] = s1c[1]; s2m[1] = s1c[5]; s2m[2] = s1c[8];
     if (!BODY || ia - 2 + g.gi0 >= 0) {
@@ -294,8 +310,8 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
     }
     march_load_stream(a, ia, in);
     // halo-table words of the columns the first iteration produces (fetched one iteration ahead, like the populations)
-    float hv1 = halo_load<float>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * 32u);
-    float hv2 = halo_load<float>(rh2, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * 32u);
+    T hv1 = halo_load<T>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);
+    T hv2 = halo_load<T>(rh2, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * HREC);
     wait_for_column(in, hv1, hv2);      // no load pending at the loop header: see wait_for_column
     int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
 #ifdef WT_M3_STAMPS
@@ -310,8 +326,8 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
         march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);               // prefetch (last one: harmless re-load)
         const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
         const int c1 = x - 1, c2 = x - 2;
-        const float hv1n = halo_load<float>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * 32u);
-        const float hv2n = halo_load<float>(rh2, hoff, (unsigned)(c2 + 1 > 0 ? c2 + 1 : 0) * 32u);
+        const T hv1n = halo_load<T>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * HREC);
+        const T hv2n = halo_load<T>(rh2, hoff, (unsigned)(c2 + 1 > 0 ? c2 + 1 : 0) * HREC);
         const Seam3 sp = seam3_fetch(m);                                       // staged by the previous iteration's store
         M3_STAMP(0);                                                           // issue of the prefetch
         STEP1(x, in, G1);                                                      // level 1 of column x
@@ -355,16 +371,16 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
         //   level 2 of NX-1 = level 1 of NX-2;  level 3 of NX-1 = level 2 of NX-2;  solid sites: own previous level reversed.
         const int co = ib;                                   // outlet column
         uint32_t solid4 = 0;
-        if (NONFAST(co)) solid4 = load_site_bytes<M3_S>(p.mask + (long)(co + 1) * g.pitch + j0);
+        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + j0);
         const bool any_solid = __ballot(solid4 != 0) != 0ULL;
         V3 L2o[9], out[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) L2o[k] = s1c[k];
-        if (any_solid) { auto own1 = [&](int k) { return G1[k]; }; march_solid<float, M3_S, false>(L2o, mac, solid4, own1); }
+        if (any_solid) { auto own1 = [&](int k) { return G1[k]; }; march_solid<T, S, false>(L2o, mac, solid4, own1); }
         // level 3 of column NX-2
         V3 t2m[3];
         t2m[0] = s2c[1]; t2m[1] = s2c[5]; t2m[2] = s2c[8];
-        const float hv2t = halo_load<float>(rh2, hoff, (unsigned)(co - 1) * 32u);
+        const T hv2t = halo_load<T>(rh2, hoff, (unsigned)(co - 1) * HREC);
         Seam3 sp = seam3_fetch(m);
         march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2t, out, mac);
         march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
@@ -374,7 +390,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
 #pragma unroll
         for (int k = 0; k < 9; k++) out[k] = G2[k];
         if (EMIT) march_outlet_macro(G2, mac);
-        if (any_solid) { auto own2 = [&](int k) { return L2o[k]; }; march_solid<float, M3_S, EMIT>(out, mac, solid4, own2); }
+        if (any_solid) { auto own2 = [&](int k) { return L2o[k]; }; march_solid<T, S, EMIT>(out, mac, solid4, own2); }
         sp = seam3_fetch(m);
         march3_store<EMIT>(m, a.voff_st, co, out, mac);
         seam3_flush(m, seam_col, sp);
@@ -388,29 +404,31 @@ __device__ __forceinline__ void march_unit3(const MarchParams<float> &p, March3A
 
 // The same machinery stopped after level 2: TWO steps per pass on the tables of the three-step plan (units, classes, H1, seam
 // buffer S3), for the one or two steps a step count leaves over after its three-step passes.
-template <bool BODY, bool EMIT, int FD>
-__device__ __forceinline__ void march_unit3_d2(const MarchParams<float> &p, March3Addr &m, __amdgpu_buffer_rsrc_t rh1, unsigned hoff, int ia, int ib,
+template <bool BODY, bool EMIT, int FD, typename T, int S>
+__device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, unsigned hoff, int ia, int ib,
                                                int uflags, int j0, int lane, bool far_win, unsigned long long nonfast_m, unsigned long long solid_m,
-                                               const float (&feq0)[9])
+                                               const T (&feq0)[9])
 {
+    typedef MV<T, S> V3;
+    constexpr unsigned HREC = 8 * sizeof(T);
     const Geom &g = p.g;
-    const MarchAddr<float, M3_S> &a = m.a;
+    const MarchAddr<T, S> &a = m.a;
 #define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 2)) & 1ULL) != 0)
 #define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 2)) & 1ULL) != 0)
-#define STEP1(x, in, G) march_step1<BODY, FD, float, M3_S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+#define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
     const int xend = ib;         // last column whose level 1 is computed
     V3 s1m[3], s1c[9];           // level 1: populations 1,5,8 of column x-2; all nine of column x-1
     V3 in[9], G1[9], mac[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) s1c[k] = mv_splat<float, M3_S>(feq0[k]);
+    for (int k = 0; k < 9; k++) s1c[k] = mv_splat<T, S>(feq0[k]);
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     if (!BODY || ia - 1 + g.gi0 >= 0) {
         march_load_stream(a, ia - 1, in);
         STEP1(ia - 1, in, s1c);
     }
     march_load_stream(a, ia, in);
-    float hv1 = halo_load<float>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * 32u);
+    T hv1 = halo_load<T>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);
     wait_for_column(in, hv1);
     int seam_col = -1;
 #pragma unroll 1
@@ -419,7 +437,7 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<float> &p, Marc
         march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has1 = x - 1 >= ia;                                         // column x-1 is an output column
         const int c1 = x - 1;
-        const float hv1n = halo_load<float>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * 32u);
+        const T hv1n = halo_load<T>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * HREC);
         const Seam3 sp = seam3_fetch(m);
         STEP1(x, in, G1);
         V3 out[9];
@@ -439,12 +457,12 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<float> &p, Marc
         // x = ib = NX-1: s1c = level 1 of NX-2, G1 = level 1 of NX-1; level 2 of the outlet column = level 1 of NX-2 (html:301-312)
         const int co = ib;
         uint32_t solid4 = 0;
-        if (NONFAST(co)) solid4 = load_site_bytes<M3_S>(p.mask + (long)(co + 1) * g.pitch + j0);
+        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + j0);
         V3 out[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) out[k] = s1c[k];
         if (EMIT) march_outlet_macro(s1c, mac);
-        if (__ballot(solid4 != 0) != 0ULL) { auto own1 = [&](int k) { return G1[k]; }; march_solid<float, M3_S, EMIT>(out, mac, solid4, own1); }
+        if (__ballot(solid4 != 0) != 0ULL) { auto own1 = [&](int k) { return G1[k]; }; march_solid<T, S, EMIT>(out, mac, solid4, own1); }
         const Seam3 sp = seam3_fetch(m);
         march3_store<EMIT>(m, a.voff_st, co, out, mac);
         seam3_flush(m, seam_col, sp);
@@ -456,9 +474,11 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<float> &p, Marc
 #undef STEP1
 }
 
-template <int DEPTH, bool EMIT, int FD>
-__global__ __launch_bounds__(256, 2) void k_march3(MarchParams<float> p)
+template <typename T, int S, int DEPTH, bool EMIT, int FD>
+__global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
 {
+    constexpr int M3_WIN = 64 * S;
+    constexpr unsigned EB = sizeof(T);
     const Geom &g = p.g;
     const int lane = threadIdx.x & 63;
     int u = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -469,18 +489,18 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<float> p)
     const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
     if (ib <= ia) return;
     const int row0 = w * M3_WIN;
-    const int j0 = row0 + lane * M3_S;
+    const int j0 = row0 + lane * S;
     const bool far_win = (w == 0) || (row0 + M3_WIN >= g.ny);
-    March3Addr m;
-    MarchAddr<float, M3_S> &a = m.a;
+    March3Addr<T, S> m;
+    MarchAddr<T, S> &a = m.a;
     a.rs = march_rsrc(p.fs, p.lat_bytes);
     a.rd = march_rsrc(p.fd, p.lat_bytes);
-    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * 4u));
-    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * 4u;
-    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * 4u : p.lat_bytes;
-    a.P4 = (unsigned)g.plane * 4u; a.pitch4 = (unsigned)g.pitch * 4u; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * 4u;
+    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * EB));
+    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * EB;
+    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * EB : p.lat_bytes;
+    a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
     a.lane = lane;
-    const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 32u;
+    const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 8u * EB;
     const __amdgpu_buffer_rsrc_t rh1 = march_rsrc(p.halo, hbytes), rh2 = march_rsrc(p.halo2, hbytes);
     unsigned hoff;
     {
@@ -488,24 +508,26 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<float> p)
         const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
         const int slot = hl < 3 ? hl : hl + 1;
         const int seam = hl < 3 ? w : w + 1;
-        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 8 + slot) * 4u;
+        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 8 + slot) * EB;
     }
     {
-        // per wave: below[40] (slot k = rows 124..127 of direction k; lane 62 writes floats 0,1, lane 63 floats 2,3; slot 9 stays
-        // zero), above[40] (lanes 0, 1), then a scratch area for the other 60 lanes
-        __shared__ __attribute__((aligned(16))) float seam_lds[4][2 * M3_SHALF + 176];
-        float *wl = &seam_lds[threadIdx.x >> 6][0];
-        m.lds_w = lane == 62 ? wl : (lane == 63 ? wl + 2 : (lane == 0 ? wl + M3_SHALF : (lane == 1 ? wl + M3_SHALF + 2 : wl + 2 * M3_SHALF + 2 * lane)));
-        m.lds_r = wl + 4 * (lane < 10 ? lane : 0);
-        if (lane < 2 * M3_SHALF / 2) { wl[lane] = 0.0f; wl[lane + M3_SHALF] = 0.0f; }
-        const unsigned sbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * 4);
+        // per wave, in elements: below[40] (slot k = the window's last four rows of direction k, staged by the last 4/S lanes; slot
+        // 9 stays zero), above[40] (rows 0..3, the first 4/S lanes), then a scratch area for the other lanes' writes
+        constexpr int EDGE = 4 / S;                       // lanes that hold four rows
+        constexpr int NCH = 10 * (int)sizeof(T) / 4;      // 16-byte chunks of one half
+        __shared__ __attribute__((aligned(16))) T seam_lds[4][2 * M3_SHALF + 176];
+        T *wl = &seam_lds[threadIdx.x >> 6][0];
+        m.lds_w = lane >= 64 - EDGE ? wl + (lane - (64 - EDGE)) * S : (lane < EDGE ? wl + M3_SHALF + lane * S : wl + 2 * M3_SHALF + S * lane);
+        m.lds_r = reinterpret_cast<const char *>(wl) + 16 * (lane < NCH ? lane : 0);
+        if (lane < M3_SHALF) { wl[lane] = T(0); wl[lane + M3_SHALF] = T(0); }
+        const unsigned sbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * EB);
         m.rs3 = march_rsrc(p.seams, sbytes);
-        const unsigned rec = (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * 4);
-        m.voff_lo = lane < 10 ? (unsigned)w * rec + (unsigned)(M3_SHALF * 4) + (unsigned)lane * 16u : sbytes;
-        m.voff_hi = lane < 10 ? (unsigned)(w + 1) * rec + (unsigned)lane * 16u : sbytes;
+        const unsigned rec = (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * EB);
+        m.voff_lo = lane < NCH ? (unsigned)w * rec + (unsigned)(M3_SHALF * EB) + (unsigned)lane * 16u : sbytes;
+        m.voff_hi = lane < NCH ? (unsigned)(w + 1) * rec + (unsigned)lane * 16u : sbytes;
     }
-    float feq0[9];
-    feq_all<float>(1.0f, p.U0, 0.0f, feq0);
+    T feq0[9];
+    feq_all<T>(T(1), p.U0, T(0), feq0);
 
     // classes of columns ia-2 .. ib+1 (lane l <-> column ia-2+l): two 64-bit scalars
     unsigned long long nonfast_m, solid_m;
@@ -519,11 +541,11 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<float> p)
     }
     const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= 3 && ib + g.gi0 <= g.nx_g - 3 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
     if (DEPTH == 3) {
-        if (lean) march_unit3<false, EMIT, FD>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
-        else march_unit3<true, EMIT, FD>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+        if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit3<true, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     } else {
-        if (lean) march_unit3_d2<false, EMIT, FD>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
-        else march_unit3_d2<true, EMIT, FD>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+        if (lean) march_unit3_d2<false, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit3_d2<true, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     }
 }
 

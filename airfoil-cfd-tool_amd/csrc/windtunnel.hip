@@ -320,7 +320,7 @@ extern "C" int wt_sync(wt_handle *h)
 static bool fuse_eligible_s(const wt_handle *h, int sites)
 {
     const unsigned long long eb = h->dtype == WT_F32 ? 4 : 8;
-    if (sites * eb != 16 && !(h->dtype == WT_F32 && sites == 2)) return false;
+    if (sites * eb != 16 && sites * eb != 8) return false;                  // 16-byte vectors (two steps per pass), 8-byte (two or three)
     return h->g.ny % sites == 0 && h->g.nxl >= 8 && 9ULL * h->g.plane * eb < (1ULL << 32) - (1ULL << 20);
 }
 static bool fuse_eligible(const wt_handle *h) { return fuse_eligible_s(h, 2) || fuse_eligible_s(h, 4); }
@@ -388,7 +388,7 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
         const long nth = (long)(nwin - 1) * g.nxl;
         if (depth == 3)
             hipLaunchKernelGGL(k_seam_flags3, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
-                               h->seam_plain, g, nwin);
+                               h->seam_plain, g, nwin, win);
         else
             hipLaunchKernelGGL(k_seam_flags, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
                                h->seam_plain, g, nwin, win);
@@ -447,15 +447,19 @@ static int rebuild_fuse_plan(wt_handle *h)
     long waves = 2;                                                      // resident marching waves per SIMD
     if (const char *e = getenv("WT_MARCH_WAVES")) waves = atoi(e) > 0 ? atoi(e) : 2;
     const long slots = (long)prop.multiProcessorCount * 4 * waves;
-    const bool depth3_ok = h->dtype == WT_F32 && fuse_eligible_s(h, 2) && h->g.nxl >= 16 && h->fuse_depth != 2 && (h->fuse_sites == 0 || h->fuse_sites == 2);
+    // three steps per pass: 8-byte vectors — fp32 with 2 sites per lane (the fp32 default), fp64 with 1 (on request: fuse_depth = 3)
+    const int s3 = h->dtype == WT_F32 ? 2 : 1;
+    const bool depth3_ok = fuse_eligible_s(h, s3) && h->g.nxl >= 16 && h->fuse_depth != 2 && (h->fuse_sites == 0 || h->fuse_sites == s3) &&
+                           (h->dtype == WT_F32 || h->fuse_depth == 3);
     if (depth3_ok) {
         const MarchRange r = march_range3(h->g);
-        const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, M3_WIN);
+        const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
         const bool force = h->fuse_force || h->fuse_depth == 3;
         if (force || h->fuse_chunk > 0 || tiles / slots >= 6) {
             long target = 2 * slots;
             if (tiles / target < 12) target = slots;
-            WT_TRY(build_fuse_plan(h, 2, target, 3));
+            while (tiles / target > MARCH_MAX_CHUNK - 4) target += slots;     // a unit holds at most MARCH_MAX_CHUNK columns: more rounds
+            WT_TRY(build_fuse_plan(h, s3, target, 3));
             h->fuse_ready = h->n_units > 0;
             return WT_OK;
         }
@@ -509,8 +513,8 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
     }
     if (strcmp(name, "fuse_depth") == 0) {
         if (!(value == 0.0 || value == 2.0 || value == 3.0)) return fail(WT_ERR_ARG, "fuse_depth must be 0 (automatic), 2 or 3");
-        if (value == 3.0 && !(h->dtype == WT_F32 && fuse_eligible_s(h, 2) && h->g.nxl >= 16))
-            return fail(WT_ERR_STATE, "fuse_depth 3 needs an fp32 handle with an even NY, at least 16 local columns and a lattice below 4 GiB");
+        if (value == 3.0 && !(fuse_eligible_s(h, h->dtype == WT_F32 ? 2 : 1) && h->g.nxl >= 16))
+            return fail(WT_ERR_STATE, "fuse_depth 3 needs at least 16 local columns, a lattice below 4 GiB and (fp32) an even NY");
         h->fuse_depth = (int)value;
         return rebuild_fuse_plan(h);
     }
@@ -840,39 +844,39 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
 
 // Three steps in one pass (step_march3.hpp), or two on the same tables (depth = 2: what a step count leaves over).
 // A = f[cur] (time t), B = f[1-cur] (receives time t + depth).
-template <int FD>
+template <typename T, int S, int FD>
 static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, int depth)
 {
     const Geom &g = h->g;
-    MarchParams<float> p;
-    p.fs = fptr<float>(h, h->cur);
-    p.fd = fptr<float>(h, 1 - h->cur);
-    p.macro = reinterpret_cast<float *>(h->macro);
+    MarchParams<T> p;
+    p.fs = fptr<T>(h, h->cur);
+    p.fd = fptr<T>(h, 1 - h->cur);
+    p.macro = reinterpret_cast<T *>(h->macro);
     p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls;
-    p.halo = reinterpret_cast<const float *>(h->halo_tab); p.halo2 = reinterpret_cast<const float *>(h->halo2);
-    p.seams = reinterpret_cast<float *>(h->seams);
+    p.halo = reinterpret_cast<const T *>(h->halo_tab); p.halo2 = reinterpret_cast<const T *>(h->halo2);
+    p.seams = reinterpret_cast<T *>(h->seams);
     p.g = g;
-    p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(float));
+    p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(T));
     p.nwin_total = h->n_win;
     p.fdv.tau = (float)tau; p.fdv.rtau = 1.0f / (float)tau;
-    p.tau = (float)tau;
-    p.U0 = (float)u0;
+    p.tau = (T)tau;
+    p.U0 = (T)u0;
     p.rev = (int)(h->passes & 1);
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
         const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H3_COLS - 1) / H3_COLS);
-        hipLaunchKernelGGL((k_halo3<FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const float *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
-                           reinterpret_cast<float *>(h->halo_tab), reinterpret_cast<float *>(h->halo2), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.U0);
+        hipLaunchKernelGGL((k_halo3<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
+                           reinterpret_cast<T *>(h->halo_tab), reinterpret_cast<T *>(h->halo2), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
     }
     p.units = h->d_units; p.nunits = h->n_units;
     if (p.nunits > 0) {
         const dim3 grid((unsigned)((p.nunits + 3) / 4));
         if (depth == 3) {
-            if (emit) hipLaunchKernelGGL((k_march3<3, true, FD>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_march3<3, false, FD>), grid, dim3(256), 0, st, p);
+            if (emit) hipLaunchKernelGGL((k_march3<T, S, 3, true, FD>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_march3<T, S, 3, false, FD>), grid, dim3(256), 0, st, p);
         } else {
-            if (emit) hipLaunchKernelGGL((k_march3<2, true, FD>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_march3<2, false, FD>), grid, dim3(256), 0, st, p);
+            if (emit) hipLaunchKernelGGL((k_march3<T, S, 2, true, FD>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_march3<T, S, 2, false, FD>), grid, dim3(256), 0, st, p);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -897,9 +901,10 @@ static inline int fuse_stride(const wt_handle *h, int left)
 static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
 {
     if (h->march_depth == 3) {
+        if (h->dtype != WT_F32) return step_triple_fused_t<double, 1, 0>(h, tau, u0, emit, k);
         bool fd = false;
         WT_TRY(fastdiv_for(h, (float)tau, &fd));
-        return fd ? step_triple_fused_t<1>(h, tau, u0, emit, k) : step_triple_fused_t<0>(h, tau, u0, emit, k);
+        return fd ? step_triple_fused_t<float, 2, 1>(h, tau, u0, emit, k) : step_triple_fused_t<float, 2, 0>(h, tau, u0, emit, k);
     }
     return step_pair_fused(h, tau, u0, emit);
 }

@@ -224,7 +224,7 @@ def main():
             eng.set_option("fuse_chunk", args.fuse_chunk)
         if args.fuse_sites > 0:
             eng.set_option("fuse_sites", args.fuse_sites)
-        if args.fuse_depth > 0 and args.dtype == "float32":
+        if args.fuse_depth > 0:
             eng.set_option("fuse_depth", args.fuse_depth)
         if args.fuse >= 0:
             eng.set_option("fuse_steps", args.fuse)

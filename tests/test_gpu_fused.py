@@ -12,7 +12,8 @@ from conftest import bits_equal
 pytestmark = pytest.mark.gpu
 
 
-COMBOS = (("float32", 4, 2), ("float32", 2, 2), ("float32", 2, 3), ("float64", 2, 2))     # dtype, sites per lane, steps per pass
+# dtype, sites per lane (0: implied by the depth), steps per pass
+COMBOS = (("float32", 4, 2), ("float32", 2, 2), ("float32", 2, 3), ("float64", 2, 2), ("float64", 0, 3))
 
 
 def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None, sites=0, dtype="float32", depth=2):
@@ -142,12 +143,13 @@ def test_fused_not_available(pkg):
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_sites", 4)           # fp64 vectors hold two sites
         with pytest.raises(pkg.WTError):
-            e.set_option("fuse_depth", 3)           # three levels of fp64 columns do not fit the register file
-        with pytest.raises(pkg.WTError):
             e.set_option("fuse_depth", 4)
         e.set_option("fuse_steps", 2)
         e.set_mask(np.zeros((128, 256), np.uint8)); e.init_equilibrium(0.06); e.step(5, 0.58, 0.06)
-        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 2
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 2       # fp64 default: two steps per pass
+        e.set_option("fuse_depth", 3)               # on request: three, with one site per lane
+        e.step(7, 0.58, 0.06)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 3 and e.get_option("fuse_sites") == 1
     with pkg.Engine(12, 64) as e:                   # fewer than 16 columns: two steps per pass at most
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_depth", 3)
@@ -209,6 +211,7 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
     (3, 7, 768, 512, [40], "float64", 2, 2),
     (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 2, 3),
     (3, 7, 768, 512, [40], "float32", 2, 3),
+    (3, 7, 768, 512, [40], "float64", 0, 3),
     (4, 17, 2048, 512, [33, 18], "float32", 2, 3),
     (2, 2, 512, 256, [9], "float32", 2, 3),              # halo 2: never three exact ghost columns -> single steps only
     (8, 16, 4096, 256, [50], "float32", 0, 0),           # automatic choice
