@@ -432,10 +432,10 @@ static long march_target_units(const wt_handle *h, int sites, long slots, bool f
     return target;
 }
 
-// Steps per pass and sites per lane.  fp32: THREE steps per pass (step_march3.hpp, 2 sites per lane) where eligible and not
-// switched off (fuse_depth = 2); otherwise two steps per pass with 4 sites per lane (256-row windows) where that plan has
-// enough units to pay, else 2 (128-row windows: twice the units — narrow lattices such as column slabs).  fp64: two steps,
-// 2 sites (16-byte vectors).  fuse_depth / fuse_sites override.  The choice depends on the geometry only, so a mask change
+// Steps per pass and sites per lane.  THREE steps per pass (step_march3.hpp: fp32 with 2 sites per lane, fp64 with 1) where
+// eligible and not switched off (fuse_depth = 2); otherwise two steps per pass — fp32 with 4 sites per lane (256-row windows)
+// where that plan has enough units to pay, else 2 (128-row windows: twice the units — narrow lattices such as column slabs);
+// fp64 with 2 sites (16-byte vectors).  fuse_depth / fuse_sites override.  The choice depends on the geometry only, so a mask change
 // rebuilds the tables in place.
 static int rebuild_fuse_plan(wt_handle *h)
 {
@@ -447,10 +447,9 @@ static int rebuild_fuse_plan(wt_handle *h)
     long waves = 2;                                                      // resident marching waves per SIMD
     if (const char *e = getenv("WT_MARCH_WAVES")) waves = atoi(e) > 0 ? atoi(e) : 2;
     const long slots = (long)prop.multiProcessorCount * 4 * waves;
-    // three steps per pass: 8-byte vectors — fp32 with 2 sites per lane (the fp32 default), fp64 with 1 (on request: fuse_depth = 3)
+    // three steps per pass (the default where it pays): 8-byte vectors — fp32 with 2 sites per lane, fp64 with 1
     const int s3 = h->dtype == WT_F32 ? 2 : 1;
-    const bool depth3_ok = fuse_eligible_s(h, s3) && h->g.nxl >= 16 && h->fuse_depth != 2 && (h->fuse_sites == 0 || h->fuse_sites == s3) &&
-                           (h->dtype == WT_F32 || h->fuse_depth == 3);
+    const bool depth3_ok = fuse_eligible_s(h, s3) && h->g.nxl >= 16 && h->fuse_depth != 2 && (h->fuse_sites == 0 || h->fuse_sites == s3);
     if (depth3_ok) {
         const MarchRange r = march_range3(h->g);
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);

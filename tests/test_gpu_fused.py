@@ -145,11 +145,11 @@ def test_fused_not_available(pkg):
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_depth", 4)
         e.set_option("fuse_steps", 2)
-        e.set_mask(np.zeros((128, 256), np.uint8)); e.init_equilibrium(0.06); e.step(5, 0.58, 0.06)
-        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 2       # fp64 default: two steps per pass
-        e.set_option("fuse_depth", 3)               # on request: three, with one site per lane
-        e.step(7, 0.58, 0.06)
-        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 3 and e.get_option("fuse_sites") == 1
+        e.set_mask(np.zeros((128, 256), np.uint8)); e.init_equilibrium(0.06); e.step(7, 0.58, 0.06)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 3 and e.get_option("fuse_sites") == 1    # fp64: one site per lane
+        e.set_option("fuse_depth", 2)
+        e.step(5, 0.58, 0.06)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 2 and e.get_option("fuse_sites") == 2
     with pkg.Engine(12, 64) as e:                   # fewer than 16 columns: two steps per pass at most
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_depth", 3)
@@ -260,9 +260,10 @@ def test_fuse_auto_only_where_it_pays(pkg):
         for e in (wide, slab, f64):
             e.set_mask(np.zeros((e.ny, e.nx_global), np.uint8)); e.init_equilibrium(0.06)
             assert e.get_option("fuse_active") == 1.0     # the default
-        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(3, 2), (3, 2), (2, 2)]
-        wide.set_option("fuse_depth", 2); slab.set_option("fuse_depth", 2)
-        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab)] == [(2, 4), (2, 2)]
+        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(3, 2), (3, 2), (3, 1)]
+        for e in (wide, slab, f64):
+            e.set_option("fuse_depth", 2)
+        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(2, 4), (2, 2), (2, 2)]
 
 
 def test_set_mask_stays_interactive(pkg):
