@@ -82,15 +82,18 @@ __global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = T(0);
         if (x >= 0 && x < g.nxl && j < g.ny) {
+            // the nine seam-buffer inputs are requested together with the flag (not behind it): this kernel is a chain of memory
+            // latencies, and the records of columns x-1 .. x+1 exist for every x (pad records at both ends)
+            T a[9];
+            const T *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int q = 2 + r4 - ey_of(k);                 // row j - ey_k relative to row 128 b - 4: 1..6
+                a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
+            }
             const bool plain = use_seams && ((flags3[(long)(b - 1) * g.nxl + x] >> r4) & 1) != 0;
             if (plain) {
-                T a[9], rho, ux, uy;
-                const T *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int q = 2 + r4 - ey_of(k);             // row j - ey_k relative to row 128 b - 4: 1..6
-                    a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
-                }
+                T rho, ux, uy;
                 collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
             } else {
                 site_step1<T, FD>(fs + g.pitch, m, g, x, j, fdv, tau, U0, o);
