@@ -68,7 +68,7 @@ def main():
         wv = wr.get(k, {}).get("WRITE_SIZE")
         rows.append([k, f, wv])
         if march3:
-            use = (k.startswith("wt::k_march3<3,false,") or k.startswith("wt::k_halo3<"))
+            use = ((k.startswith("wt::k_march3<") and ",3,false," in k) or k.startswith("wt::k_halo3<"))
         elif march:
             use = ((k.startswith("wt::k_march<") and ",false," in k) or k.startswith("wt::k_halo_from_seams"))
         else:
