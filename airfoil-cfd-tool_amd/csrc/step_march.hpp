@@ -274,6 +274,7 @@ struct MarchParams {
     const uint8_t *wcls;       // window-tile classes [nwin][nxl + 2]
     const T *halo;             // H[nwin + 1][nxl + 2][8], see k_halo_rows
     const T *halo2;            // three-step passes only (step_march3.hpp): the level-2 halo table
+    const T *halo3;            // four-step passes only: the level-3 halo table
     T *seams;                  // S[nwin + 1][nxl + 2][2][24]: the rows around every window seam of the DESTINATION lattice, see k_halo_from_seams
     const MarchUnit *units;
     int nunits;
@@ -885,8 +886,10 @@ struct MarchPlan {
 // COST — a FAST column costs 1, any other column 1 + alpha (its step 1 waits for nine more loads) — such that
 // the total is at most `target_units` (a multiple of `slots` chosen by the caller), or, when max_cost > 0, into
 // units of at most max_cost (tests, experiments).
+// min_last: least number of marched columns of a window's LAST unit (a four-step pass needs 2: the unit before the outlet unit
+// must end two columns short of the outlet column); max_len: most columns of a unit.
 static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int win, long target_units, int max_cost = 0, double alpha = 1.0,
-                                         const MarchRange *range = nullptr)
+                                         const MarchRange *range = nullptr, int min_last = 1, int max_len = MARCH_MAX_CHUNK)
 {
     MarchPlan pl;
     const int nwin = march_nwin(g.ny, win), ld = g.nxl + 2;
@@ -907,7 +910,7 @@ static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int
         if (target_units < nwin) target_units = nwin;
         target = total / (double)target_units;
     }
-    if (target > (double)MARCH_MAX_CHUNK) target = (double)MARCH_MAX_CHUNK;      // a unit's class bytes must fit one wave
+    if (target > (double)max_len) target = (double)max_len;      // a unit's class bytes must fit one wave
     if (target < 1.0) target = 1.0;
     pl.chunk = (int)(target + 0.5);
     for (int w = 0; w < nwin; w++) {
@@ -922,7 +925,8 @@ static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int
         for (int x = r.i_begin; x < r.i_end; x++) {
             acc += (c[x] == WC_FAST) ? 1.0 : 1.0 + alpha;
             const bool last = (x + 1 == r.i_end);
-            if (last || (done + 1 < parts && acc >= per * (done + 1) - 1e-9) || x + 1 - ia >= MARCH_MAX_CHUNK) {
+            const bool tail_short = !last && r.i_end - (x + 1) < min_last;      // a cut here would leave too short a last unit
+            if (last || (!tail_short && ((done + 1 < parts && acc >= per * (done + 1) - 1e-9) || x + 1 - ia >= max_len))) {
                 pl.units.push_back(MarchUnit{ia, x + 1, w, (r.outlet_after && last) ? MU_OUTLET_AFTER : 0});
                 ia = x + 1;
                 done++;

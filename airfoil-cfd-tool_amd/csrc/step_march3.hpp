@@ -150,6 +150,144 @@ __global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T
 }
 
 // ------------------------------------------------------------------------------------------------
+// FOUR steps per pass: the halo tables H1, H2, H3
+// ------------------------------------------------------------------------------------------------
+// flags4[(b - 1) * nxl + x], bit r6 set <=> site (x, WIN b - 3 + r6) is plain interior fluid (see k_seam_flags3)
+__global__ __launch_bounds__(256) void k_seam_flags4(const uint8_t *__restrict__ mask, const uint8_t *__restrict__ bcode, uint8_t *__restrict__ flags4,
+                                                     Geom g, int nwin, int win)
+{
+    const long total = (long)(nwin - 1) * g.nxl;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int x = (int)(t % g.nxl);
+    const int b = 1 + (int)(t / g.nxl);
+    const uint8_t *m = mask + g.pitch;
+    const int gi = x + g.gi0;
+    unsigned f = 0;
+    for (int r6 = 0; r6 < 6; r6++) {
+        const int j = win * b - 3 + r6;
+        if (j <= 0 || j >= g.ny - 1 || gi <= 0 || gi >= g.nx_g - 1) continue;
+        const long c = (long)x * g.pitch + j;
+        if (m[c] == 0 && bcode[c] == 0) f |= 1u << r6;
+    }
+    flags4[t] = (uint8_t)f;
+}
+
+// STEP_FS (html:283-360), every branch in the reference's order, for site (x, j) on the previous level's values:
+// get(k, dx, dy) = population k of site (x + dx, j + dy) one level down
+template <typename T, int FD, typename GET>
+__device__ __forceinline__ void halo_step(const uint8_t *__restrict__ m, const Geom &g, int x, int j, bool plain, GET get, const FastDiv &fdv, T tau, T U0,
+                                          T (&o)[9])
+{
+    if (j >= g.ny || x < 0 || x >= g.nxl) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = T(0);
+        return;
+    }
+    const long c = (long)x * g.pitch + j;
+    const int gi = x + g.gi0;
+    if (plain) {                                                       // plain interior fluid: html:324-359 without the mask reads
+        T fin[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) fin[k] = get(k, -ex_of(k), -ey_of(k));
+        collide_t<T, FD>(fin, fdv, tau, o, rho, ux, uy);
+    } else if (m[c]) {                                                 // html:287-294 solid
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = get(opp_of(k), 0, 0);
+    } else if (gi == g.nx_g - 1) {                                     // html:301-312 outlet
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = get(k, -1, 0);
+    } else if (gi == 0 || j == g.ny - 1 || j == 0) {                   // html:314-322 far field
+        feq_all<T>(T(1), U0, T(0), o);
+    } else {                                                           // html:324-359 interior fluid
+        T fin[9], rho, ux, uy;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
+            fin[k] = m[src] ? get(opp_of(k), 0, 0) : get(k, -ex_of(k), -ey_of(k));
+        }
+        collide_t<T, FD>(fin, fdv, tau, o, rho, ux, uy);
+    }
+}
+
+// One block = one seam x 60 columns.  Level 1 of rows WIN b - 3 .. WIN b + 2 (six rows) x 64 columns from the seam buffer / the
+// lattice, level 2 of rows WIN b - 2 .. WIN b + 1 x 62 columns, level 3 of rows WIN b - 1, WIN b x 60 columns, in LDS; H1, H2, H3
+// take the two rows next to the seam of each level (layout as in k_halo3).
+static constexpr int H4_COLS = 60;
+template <typename T, int S, int FD>
+__global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
+                                               const uint8_t *__restrict__ flags4, T *__restrict__ h1, T *__restrict__ h2, T *__restrict__ h3, Geom g,
+                                               int nwin, int use_seams, FastDiv fdv, T tau, T U0)
+{
+    constexpr int WIN = 64 * S;
+    __shared__ T l1[64][6][9 + 1];
+    __shared__ T l2[64][4][9 + 1];
+    const int nblk_x = (g.nxl + H4_COLS - 1) / H4_COLS;
+    const int b = 1 + (int)(blockIdx.x / nblk_x);
+    const int x0 = (int)(blockIdx.x % nblk_x) * H4_COLS;          // first output column; l1 / l2 column index cl <-> x0 - 2 + cl
+    const uint8_t *m = mask + g.pitch;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    // ---- level 1: 64 columns x 6 rows
+    for (int w = threadIdx.x; w < 64 * 6; w += 256) {
+        const int cl = w / 6, r6 = w % 6;
+        const int x = x0 - 2 + cl;
+        const int j = WIN * b - 3 + r6;
+        T o[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = T(0);
+        if (x >= 0 && x < g.nxl && j < g.ny) {
+            T a[9];
+            const T *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int q = 1 + r6 - ey_of(k);                 // row j - ey_k relative to row WIN b - 4: 0..7
+                a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
+            }
+            const bool plain = use_seams && ((flags4[(long)(b - 1) * g.nxl + x] >> r6) & 1) != 0;
+            if (plain) {
+                T rho, ux, uy;
+                collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
+            } else {
+                site_step1<T, FD>(fs + g.pitch, m, g, x, j, fdv, tau, U0, o);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) l1[cl][r6][k] = o[k];
+    }
+    __syncthreads();
+    // ---- level 2: columns cl = 1..62, rows WIN b - 2 + r4
+    if (threadIdx.x < 62 * 4) {
+        const int cl = 1 + threadIdx.x / 4, r4 = threadIdx.x % 4;
+        const int x = x0 - 2 + cl;
+        const int j = WIN * b - 2 + r4;
+        const bool inside = x >= 0 && x < g.nxl;
+        const bool plain = inside && ((flags4[(long)(b - 1) * g.nxl + x] >> (r4 + 1)) & 1) != 0;
+        auto get = [&](int k, int dx, int dy) { return l1[cl + dx][r4 + 1 + dy][k]; };
+        T o[9];
+        halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
+#pragma unroll
+        for (int k = 0; k < 9; k++) l2[cl][r4][k] = o[k];
+    }
+    __syncthreads();
+    // ---- level 3 and the three tables: columns cl = 2..61, side 0 = row WIN b - 1, side 1 = row WIN b
+    if (threadIdx.x < H4_COLS * 2) {
+        const int cl = 2 + threadIdx.x / 2, side = threadIdx.x & 1;
+        const int x = x0 - 2 + cl;
+        if (x >= g.nxl) return;
+        const int j = WIN * b - 1 + side;
+        const bool plain = ((flags4[(long)(b - 1) * g.nxl + x] >> (2 + side)) & 1) != 0;
+        auto get = [&](int k, int dx, int dy) { return l2[cl + dx][1 + side + dy][k]; };
+        T o[9];
+        halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
+        const long rec = ((long)b * (g.nxl + 2) + x + 1) * 8 + side * 4;
+        const T *p1 = l1[cl][2 + side], *p2 = l2[cl][1 + side];
+        *reinterpret_cast<t4 *>(h1 + rec) = side ? t4{p1[4], p1[7], p1[8], T(0)} : t4{p1[2], p1[5], p1[6], T(0)};
+        *reinterpret_cast<t4 *>(h2 + rec) = side ? t4{p2[4], p2[7], p2[8], T(0)} : t4{p2[2], p2[5], p2[6], T(0)};
+        *reinterpret_cast<t4 *>(h3 + rec) = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // the marching kernel
 // ------------------------------------------------------------------------------------------------
 
@@ -241,7 +379,7 @@ __device__ __forceinline__ void march3_store(const March3Addr<T, S> &m, unsigned
 // has nothing younger in flight, and the merged counter state keeps that — which also waits for the eleven stores just
 // issued: every iteration then ends by draining its own stores.
 template <typename T, int S>
-__device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1 = T(0), T h2 = T(0))
+__device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1 = T(0), T h2 = T(0), T h3 = T(0))
 {
 #ifdef WT_M3_NOWAIT          // experiments: leave the waits to hipcc
     return;
@@ -249,7 +387,7 @@ __device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1 = T
     u2v r[9];                // the raw 8 bytes of every vector: the same registers, whatever T and S are
 #pragma unroll
     for (int k = 0; k < 9; k++) __builtin_memcpy(&r[k], &c[k], 8);
-    asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(r[8]), "v"(h1), "v"(h2));
+    asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(r[8]), "v"(h1), "v"(h2), "v"(h3));
 }
 // ... and keep it from drifting upwards: an asm that reads the column about to be stored is ordered before the one above
 template <typename T, int S>
@@ -405,6 +543,130 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 #undef STEP1
 }
 
+// FOUR steps per pass: one more level (s3m / s3c) and one more stage than march_unit3; the pipeline starts one column earlier
+// (level 2 of column ia-2 is needed) and delivers level 4 of column x-3.  Columns ia-3 .. ib+2 take part: class masks are indexed
+// by x - ia + 3.
+template <bool BODY, bool EMIT, int FD, typename T, int S>
+__device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, __amdgpu_buffer_rsrc_t rh2,
+                                            __amdgpu_buffer_rsrc_t rh3, unsigned hoff, int ia, int ib, int uflags, int j0, int lane, bool far_win,
+                                            unsigned long long nonfast_m, unsigned long long solid_m, const T (&feq0)[9])
+{
+    typedef MV<T, S> V3;
+    constexpr unsigned HREC = 8 * sizeof(T);
+    const Geom &g = p.g;
+    const MarchAddr<T, S> &a = m.a;
+    // (the level-4 stage of the first iteration works on column ia-4, outside the masks: no class -> plain / inlet branch, no mask access)
+#define NONFAST(x) (BODY && (x) >= ia - 3 && ((nonfast_m >> ((x) - ia + 3)) & 1ULL) != 0)
+#define ALLSOLID(x) (BODY && (x) >= ia - 3 && ((solid_m >> ((x) - ia + 3)) & 1ULL) != 0)
+#define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+#define HCOL(c) ((unsigned)((c) > 0 ? (c) : 0) * HREC)
+    const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
+    const int xend = outlet ? ib : ib + 2;       // last column whose level 1 is computed
+    V3 s1m[3], s1c[9];           // level 1: populations 1,5,8 of column x-2; all nine of column x-1
+    V3 s2m[3], s2c[9];           // level 2: ... of column x-3; x-2
+    V3 s3m[3], s3c[9];           // level 3: ... of column x-4; x-3
+    V3 in[9], G1[9], G2[9], G3[9], mac[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s1c[k] = mv_splat<T, S>(feq0[k]); s2c[k] = s1c[k]; s3c[k] = s1c[k]; }
+    s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+    s2m[0] = s1c[1]; s2m[1] = s1c[5]; s2m[2] = s1c[8];
+    s3m[0] = s1c[1]; s3m[1] = s1c[5]; s3m[2] = s1c[8];
+    // ---- prologue: level 1 of columns ia-3 and ia-2 (columns left of the inlet do not exist: the far-field value stands in)
+    if (!BODY || ia - 3 + g.gi0 >= 0) {
+        march_load_stream(a, ia - 3, in);
+        STEP1(ia - 3, in, s1c);
+    }
+    s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+    if (!BODY || ia - 2 + g.gi0 >= 0) {
+        march_load_stream(a, ia - 2, in);
+        STEP1(ia - 2, in, s1c);
+    }
+    const int xs = ia - 1;       // first loop column; when it lies left of the inlet its loads go to the inlet column (values unused)
+#define LCOL(x) ((BODY && (x) + g.gi0 < 0) ? -g.gi0 : (x))
+    march_load_stream(a, LCOL(xs), in);
+    T hv1 = halo_load<T>(rh1, hoff, HCOL(xs - 1)), hv2 = halo_load<T>(rh2, hoff, HCOL(xs - 2)), hv3 = halo_load<T>(rh3, hoff, HCOL(xs - 3));
+    wait_for_column(in, hv1, hv2, hv3);
+    int seam_col = -1;
+#pragma unroll 1
+    for (int x = xs; x <= xend; x++) {
+        V3 nxt[9];
+        march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);
+        const bool has3 = x - 3 >= ia;                                         // column x-3 is an output column
+        const int c1 = x - 1, c2 = x - 2, c3 = x - 3;
+        const T hv1n = halo_load<T>(rh1, hoff, HCOL(c1 + 1)), hv2n = halo_load<T>(rh2, hoff, HCOL(c2 + 1)), hv3n = halo_load<T>(rh3, hoff, HCOL(c3 + 1));
+        const Seam3 sp = seam3_fetch(m);
+        STEP1(x, in, G1);                                                      // level 1 of column x
+        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac);     // level 2 of x-1
+        march_stage<BODY, false, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, G3, mac);     // level 3 of x-2
+        V3 out[9];
+        march_stage<BODY, EMIT, FD>(p, c3, j0, lane, far_win, NONFAST(c3), ALLSOLID(c3), feq0, s3m, s3c, G3, hv3, out, mac);     // level 4 of x-3
+        pin_after(out);
+        wait_for_column(nxt, hv1n, hv2n, hv3n);
+        hv1 = hv1n; hv2 = hv2n; hv3 = hv3n;
+        march3_store<EMIT>(m, has3 ? a.voff_st : p.lat_bytes, has3 ? c3 : 0, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = has3 ? c3 : seam_col;
+        if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
+        s3m[0] = s3c[1]; s3m[1] = s3c[5]; s3m[2] = s3c[8];
+        s2m[0] = s2c[1]; s2m[1] = s2c[5]; s2m[2] = s2c[8];
+        s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { s3c[k] = G3[k]; s2c[k] = G2[k]; s1c[k] = G1[k]; in[k] = nxt[k]; }
+    }
+    if (BODY && outlet) {
+        // x = ib = NX-1 = co (local).  Held: level 1 of co-1 (s1c) and co (G1); level 2 of co-2 (s2c) and co-1 (G2); level 3 of co-3
+        // (s3c) and co-2 (G3); level 4 of co-3 is stored.  Outlet rule (html:301-312): level k+1 of co = level k of co-1; its solid
+        // sites: own level k reversed.
+        const int co = ib;
+        uint32_t solid4 = 0;
+        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + j0);
+        const bool any_solid = __ballot(solid4 != 0) != 0ULL;
+        V3 O2[9], O3[9], L3a[9], out[9], tm[3];
+        // level 2 of co
+#pragma unroll
+        for (int k = 0; k < 9; k++) O2[k] = s1c[k];
+        if (any_solid) { auto own = [&](int k) { return G1[k]; }; march_solid<T, S, false>(O2, mac, solid4, own); }
+        // level 3 of co-1
+        tm[0] = s2c[1]; tm[1] = s2c[5]; tm[2] = s2c[8];
+        march_stage<BODY, false, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, G2, O2, halo_load<T>(rh2, hoff, HCOL(co - 1)), L3a, mac);
+        // level 3 of co
+#pragma unroll
+        for (int k = 0; k < 9; k++) O3[k] = G2[k];
+        if (any_solid) { auto own = [&](int k) { return O2[k]; }; march_solid<T, S, false>(O3, mac, solid4, own); }
+        // level 4 of co-2
+        tm[0] = s3c[1]; tm[1] = s3c[5]; tm[2] = s3c[8];
+        Seam3 sp = seam3_fetch(m);
+        // (a last unit of a single marched column does not own column co-2, and its level 3 of co-3 is not valid: drop the stores)
+        const bool own2 = co - 2 >= ia;
+        march_stage<BODY, EMIT, FD>(p, co - 2, j0, lane, far_win, NONFAST(co - 2), ALLSOLID(co - 2), feq0, tm, G3, L3a, halo_load<T>(rh3, hoff, HCOL(co - 2)), out, mac);
+        march3_store<EMIT>(m, own2 ? a.voff_st : p.lat_bytes, own2 ? co - 2 : 0, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = own2 ? co - 2 : seam_col;
+        // level 4 of co-1
+        tm[0] = G3[1]; tm[1] = G3[5]; tm[2] = G3[8];
+        sp = seam3_fetch(m);
+        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, L3a, O3, halo_load<T>(rh3, hoff, HCOL(co - 1)), out, mac);
+        march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = co - 1;
+        // level 4 of co
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = L3a[k];
+        if (EMIT) march_outlet_macro(L3a, mac);
+        if (any_solid) { auto own = [&](int k) { return O3[k]; }; march_solid<T, S, EMIT>(out, mac, solid4, own); }
+        sp = seam3_fetch(m);
+        march3_store<EMIT>(m, a.voff_st, co, out, mac);
+        seam3_flush(m, seam_col, sp);
+        seam_col = co;
+    }
+    seam3_flush(m, seam_col, seam3_fetch(m));
+#undef NONFAST
+#undef ALLSOLID
+#undef STEP1
+#undef HCOL
+#undef LCOL
+}
+
 // The same machinery stopped after level 2: TWO steps per pass on the tables of the three-step plan (units, classes, H1, seam
 // buffer S3), for the one or two steps a step count leaves over after its three-step passes.
 template <bool BODY, bool EMIT, int FD, typename T, int S>
@@ -504,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
     a.lane = lane;
     const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 8u * EB;
-    const __amdgpu_buffer_rsrc_t rh1 = march_rsrc(p.halo, hbytes), rh2 = march_rsrc(p.halo2, hbytes);
+    const __amdgpu_buffer_rsrc_t rh1 = march_rsrc(p.halo, hbytes), rh2 = march_rsrc(p.halo2, hbytes), rh3 = march_rsrc(p.halo3, hbytes);
     unsigned hoff;
     {
         const int hl = lane < 6 ? lane : 0;
@@ -532,18 +794,22 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     T feq0[9];
     feq_all<T>(T(1), p.U0, T(0), feq0);
 
-    // classes of columns ia-2 .. ib+1 (lane l <-> column ia-2+l): two 64-bit scalars
+    // classes of columns ia-PAD .. ib+PAD-1 (lane l <-> column ia-PAD+l): two 64-bit scalars
+    constexpr int PAD = DEPTH == 4 ? 3 : 2;
     unsigned long long nonfast_m, solid_m;
     {
-        const int n = ib - ia + 4;
-        const int col = ia - 2 + lane;
+        const int n = ib - ia + 2 * PAD;
+        const int col = ia - PAD + lane;
         uint8_t cls = WC_FAST;
         if (lane < n && col >= -1 && col <= g.nxl) cls = p.wcls[(long)w * (g.nxl + 2) + col + 1];
         nonfast_m = __ballot(cls != WC_FAST);
         solid_m = __ballot(cls == WC_SOLID);
     }
-    const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= 3 && ib + g.gi0 <= g.nx_g - 3 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
-    if (DEPTH == 3) {
+    const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= PAD + 1 && ib + g.gi0 <= g.nx_g - PAD - 1 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
+    if (DEPTH == 4) {
+        if (lean) march_unit4<false, EMIT, FD, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit4<true, EMIT, FD, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+    } else if (DEPTH == 3) {
         if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
         else march_unit3<true, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     } else {
@@ -554,12 +820,12 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
 
 // Marched column range of a three-step pass: global edges as in march_range; a local slab edge loses THREE columns of
 // validity per pass, and level 2 of column 1 would need column -2: the two columns next to a local edge are left alone.
-static inline MarchRange march_range3(const Geom &g)
+static inline MarchRange march_range3(const Geom &g, int depth = 3)
 {
     MarchRange r;
-    r.i_begin = (g.gi0 == 0) ? 0 : 2;
+    r.i_begin = (g.gi0 == 0) ? 0 : depth - 1;
     r.outlet_after = (g.gi0 + g.nxl == g.nx_g) ? 1 : 0;
-    r.i_end = r.outlet_after ? g.nxl - 1 : g.nxl - 2;
+    r.i_end = r.outlet_after ? g.nxl - 1 : g.nxl - (depth - 1);
     return r;
 }
 

@@ -100,7 +100,8 @@ struct wt_handle {
     int fuse_sites = 0;                  // option: sites per lane of the marching kernel (0 = automatic; 2 or 4)
     int fuse_depth = 0;                  // option: steps per pass (0 = automatic; 2 or 3)
     int march_depth = 0;                 // steps per pass in use (3: step_march3.hpp, fp32 with 2 sites per lane)
-    void *halo2 = nullptr;               // depth 3: level-2 halo table
+    void *halo2 = nullptr;               // depth 3 / 4: level-2 halo table
+    void *halo3 = nullptr;               // depth 4: level-3 halo table
     long long passes = 0;
     long long march_table_bytes = 0;     // wcls + halo_tab + seams + seam_plain (part of device_bytes)
     int march_s = 0;                     // sites per lane in use (4: fp32 256-row windows; 2: fp64, or fp32 on narrow lattices)
@@ -332,6 +333,7 @@ static void free_march_tables(wt_handle *h)
     if (h->seams) { (void)hipFree(h->seams); h->seams = nullptr; }
     if (h->seam_plain) { (void)hipFree(h->seam_plain); h->seam_plain = nullptr; }
     if (h->halo2) { (void)hipFree(h->halo2); h->halo2 = nullptr; }
+    if (h->halo3) { (void)hipFree(h->halo3); h->halo3 = nullptr; }
     h->seams_valid = false;
     h->n_win = 0;
     h->device_bytes -= h->march_table_bytes;
@@ -357,17 +359,23 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
         added += (long long)hbytes;
     }
     if (!h->seams) {
-        const size_t sbytes = (size_t)(nwin + 1) * (g.nxl + 2) * (depth == 3 ? M3_SREC : 48) * eb;
+        const size_t sbytes = (size_t)(nwin + 1) * (g.nxl + 2) * (depth >= 3 ? M3_SREC : 48) * eb;
         HIP_TRY(hipMalloc(&h->seams, sbytes));
         HIP_TRY(hipMemsetAsync(h->seams, 0, sbytes, h->s_compute));
         h->seams_valid = false;
         added += (long long)sbytes;
     }
     if (!h->seam_plain && nwin > 1) { HIP_TRY(hipMalloc((void **)&h->seam_plain, (size_t)(nwin - 1) * g.nxl)); added += (long long)(nwin - 1) * g.nxl; }
-    if (depth == 3 && !h->halo2) {
+    if (depth >= 3 && !h->halo2) {
         const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb;
         HIP_TRY(hipMalloc(&h->halo2, hbytes));
         HIP_TRY(hipMemsetAsync(h->halo2, 0, hbytes, h->s_compute));
+        added += (long long)hbytes;
+    }
+    if (depth == 4 && !h->halo3) {
+        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb;
+        HIP_TRY(hipMalloc(&h->halo3, hbytes));
+        HIP_TRY(hipMemsetAsync(h->halo3, 0, hbytes, h->s_compute));
         added += (long long)hbytes;
     }
     h->march_table_bytes += added;
@@ -386,7 +394,10 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->bcode, g);
     if (nwin > 1) {
         const long nth = (long)(nwin - 1) * g.nxl;
-        if (depth == 3)
+        if (depth == 4)
+            hipLaunchKernelGGL(k_seam_flags4, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
+                               h->seam_plain, g, nwin, win);
+        else if (depth == 3)
             hipLaunchKernelGGL(k_seam_flags3, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
                                h->seam_plain, g, nwin, win);
         else
@@ -398,8 +409,10 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     HIP_TRY(hipMemcpyAsync(h->host_wcls.data(), h->wcls, wbytes, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
 
-    const MarchRange r = depth == 3 ? march_range3(g) : march_range(g);
-    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, 2.0, &r);
+    const MarchRange r = depth >= 3 ? march_range3(g, depth) : march_range(g);
+    // four steps per pass: class masks cover ib - ia + 6 columns, and the last unit of a window marches at least two
+    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, 2.0, &r, depth == 4 ? 2 : 1,
+                                          depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK);
     const size_t total = pl.units.size();
     if (total == 0) return WT_OK;
     if (total > h->units_cap) {
@@ -451,19 +464,20 @@ static int rebuild_fuse_plan(wt_handle *h)
     const int s3 = h->dtype == WT_F32 ? 2 : 1;
     const bool depth3_ok = fuse_eligible_s(h, s3) && h->g.nxl >= 16 && h->fuse_depth != 2 && (h->fuse_sites == 0 || h->fuse_sites == s3);
     if (depth3_ok) {
-        const MarchRange r = march_range3(h->g);
+        const int depth = h->fuse_depth == 4 ? 4 : 3;
+        const MarchRange r = march_range3(h->g, depth);
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
-        const bool force = h->fuse_force || h->fuse_depth == 3;
+        const bool force = h->fuse_force || h->fuse_depth >= 3;
         if (force || h->fuse_chunk > 0 || tiles / slots >= 6) {
             long target = 2 * slots;
             if (tiles / target < 12) target = slots;
-            while (tiles / target > MARCH_MAX_CHUNK - 4) target += slots;     // a unit holds at most MARCH_MAX_CHUNK columns: more rounds
-            WT_TRY(build_fuse_plan(h, s3, target, 3));
+            while (tiles / target > MARCH_MAX_CHUNK - 6) target += slots;     // a unit holds at most MARCH_MAX_CHUNK columns: more rounds
+            WT_TRY(build_fuse_plan(h, s3, target, depth));
             h->fuse_ready = h->n_units > 0;
             return WT_OK;
         }
     }
-    if (h->fuse_depth == 3) return WT_OK;
+    if (h->fuse_depth >= 3) return WT_OK;
     int order[2] = {4, 2}, n = 2;
     if (h->dtype != WT_F32) { order[0] = 2; n = 1; }
     else if (h->fuse_sites == 2 || h->fuse_sites == 4) { order[0] = h->fuse_sites; n = 1; }
@@ -511,9 +525,9 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         return rebuild_fuse_plan(h);
     }
     if (strcmp(name, "fuse_depth") == 0) {
-        if (!(value == 0.0 || value == 2.0 || value == 3.0)) return fail(WT_ERR_ARG, "fuse_depth must be 0 (automatic), 2 or 3");
-        if (value == 3.0 && !(fuse_eligible_s(h, h->dtype == WT_F32 ? 2 : 1) && h->g.nxl >= 16))
-            return fail(WT_ERR_STATE, "fuse_depth 3 needs at least 16 local columns, a lattice below 4 GiB and (fp32) an even NY");
+        if (!(value == 0.0 || value == 2.0 || value == 3.0 || value == 4.0)) return fail(WT_ERR_ARG, "fuse_depth must be 0 (automatic), 2, 3 or 4");
+        if (value >= 3.0 && !(fuse_eligible_s(h, h->dtype == WT_F32 ? 2 : 1) && h->g.nxl >= 16))
+            return fail(WT_ERR_STATE, "fuse_depth 3 / 4 needs at least 16 local columns, a lattice below 4 GiB and (fp32) an even NY");
         h->fuse_depth = (int)value;
         return rebuild_fuse_plan(h);
     }
@@ -852,7 +866,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.fd = fptr<T>(h, 1 - h->cur);
     p.macro = reinterpret_cast<T *>(h->macro);
     p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls;
-    p.halo = reinterpret_cast<const T *>(h->halo_tab); p.halo2 = reinterpret_cast<const T *>(h->halo2);
+    p.halo = reinterpret_cast<const T *>(h->halo_tab); p.halo2 = reinterpret_cast<const T *>(h->halo2); p.halo3 = reinterpret_cast<const T *>(h->halo3);
     p.seams = reinterpret_cast<T *>(h->seams);
     p.g = g;
     p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(T));
@@ -863,14 +877,24 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.rev = (int)(h->passes & 1);
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
-        const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H3_COLS - 1) / H3_COLS);
-        hipLaunchKernelGGL((k_halo3<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
-                           reinterpret_cast<T *>(h->halo_tab), reinterpret_cast<T *>(h->halo2), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
+        if (h->march_depth == 4) {      // the plan's tables are those of the four-step pass, whatever this pass advances
+            const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H4_COLS - 1) / H4_COLS);
+            hipLaunchKernelGGL((k_halo4<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
+                               reinterpret_cast<T *>(h->halo_tab), reinterpret_cast<T *>(h->halo2), reinterpret_cast<T *>(h->halo3), g, h->n_win,
+                               h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
+        } else {
+            const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H3_COLS - 1) / H3_COLS);
+            hipLaunchKernelGGL((k_halo3<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
+                               reinterpret_cast<T *>(h->halo_tab), reinterpret_cast<T *>(h->halo2), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
+        }
     }
     p.units = h->d_units; p.nunits = h->n_units;
     if (p.nunits > 0) {
         const dim3 grid((unsigned)((p.nunits + 3) / 4));
-        if (depth == 3) {
+        if (depth == 4) {
+            if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
+        } else if (depth == 3) {
             if (emit) hipLaunchKernelGGL((k_march3<T, S, 3, true, FD>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((k_march3<T, S, 3, false, FD>), grid, dim3(256), 0, st, p);
         } else {
@@ -893,13 +917,14 @@ static inline int fuse_stride(const wt_handle *h, int left)
 {
     if (!h->fuse_ready) return 0;
     const int avail = h->nranks == 1 ? left : (left < h->ghost_valid ? left : h->ghost_valid);
+    if (h->march_depth == 4) return avail >= 4 ? 4 : (avail >= 2 ? avail : 0);
     if (h->march_depth == 3) return avail >= 3 ? 3 : (avail >= 2 ? 2 : 0);
     return avail >= 2 ? 2 : 0;
 }
 
 static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
 {
-    if (h->march_depth == 3) {
+    if (h->march_depth >= 3) {
         if (h->dtype != WT_F32) return step_triple_fused_t<double, 1, 0>(h, tau, u0, emit, k);
         bool fd = false;
         WT_TRY(fastdiv_for(h, (float)tau, &fd));

@@ -69,7 +69,7 @@ def parse_args():
                          "default (on where it pays), 0 off, 1 where it pays, 2 always")
     ap.add_argument("--fuse-chunk", type=int, default=0, help="cost limit of a marching unit in columns (0 = whole resident rounds)")
     ap.add_argument("--fuse-sites", type=int, default=0, choices=[0, 2, 4], help="sites per lane of the marching kernel (0 = automatic)")
-    ap.add_argument("--fuse-depth", type=int, default=0, choices=[0, 2, 3], help="steps per pass of the marching kernel (0 = automatic)")
+    ap.add_argument("--fuse-depth", type=int, default=0, choices=[0, 2, 3, 4], help="steps per pass of the marching kernel (0 = automatic)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -281,11 +281,13 @@ def main():
     sites_per_launch = eng.width * ny if not distributed else (nx_total // world) * ny
     key = f"{nx_total}x{ny}_{args.dtype}"
     main_kernel = "wt::k_step"
-    if fused and steps_per_launch == 3:
+    if fused and steps_per_launch == 4:
+        main_kernel = "wt::k_march3<..,4,..> (FOUR steps per pass, body / inlet / outlet inside; + wt::k_halo4 per pass)"
+    elif fused and steps_per_launch == 3:
         main_kernel = "wt::k_march3 (THREE steps per pass, body / inlet / outlet inside; + wt::k_halo3 per pass)"
     elif fused:
         main_kernel = "wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)"
-    traffic = None if distributed else measured_traffic(key + (("_march3" if steps_per_launch == 3 else "_march") if fused else ""))
+    traffic = None if distributed else measured_traffic(key + (("_march4" if steps_per_launch == 4 else "_march3" if steps_per_launch == 3 else "_march") if fused else ""))
     r = roofline_entry(main_kernel, bpl * sites_per_launch * steps_per_launch, launch_ms, traffic)
     # `achieved` is the REAL HBM rate (counters) when this workload has been profiled, else the effective rate
     basis = "counters" if r["counter_gbps"] is not None else "effective"

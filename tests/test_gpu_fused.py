@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 # dtype, sites per lane (0: implied by the depth), steps per pass
-COMBOS = (("float32", 4, 2), ("float32", 2, 2), ("float32", 2, 3), ("float64", 2, 2), ("float64", 0, 3))
+COMBOS = (("float32", 4, 2), ("float32", 2, 2), ("float32", 2, 3), ("float32", 2, 4), ("float64", 2, 2), ("float64", 0, 3), ("float64", 0, 4))
 
 
 def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None, sites=0, dtype="float32", depth=2):
@@ -89,7 +89,7 @@ def test_fused_low_tau_clamp_and_mask_change(pkg, oracle_c):
     m1, m2 = _body(pkg, nx, ny, "naca4412", 20.0), _body(pkg, nx, ny, "naca4412", 5.0)
     fr, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float32)
     fr, mr = oracle_c.run(m2, 100, 0.5004, 0.09, np.float32, f=fr)
-    for sites, depth in ((4, 2), (2, 2), (2, 3)):
+    for sites, depth in ((4, 2), (2, 2), (2, 3), (2, 4)):
         with pkg.Engine(nx, ny) as e:
             e.set_option("fuse_sites", sites)
             e.set_option("fuse_depth", depth)
@@ -143,7 +143,7 @@ def test_fused_not_available(pkg):
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_sites", 4)           # fp64 vectors hold two sites
         with pytest.raises(pkg.WTError):
-            e.set_option("fuse_depth", 4)
+            e.set_option("fuse_depth", 5)
         e.set_option("fuse_steps", 2)
         e.set_mask(np.zeros((128, 256), np.uint8)); e.init_equilibrium(0.06); e.step(7, 0.58, 0.06)
         assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 3 and e.get_option("fuse_sites") == 1    # fp64: one site per lane
@@ -212,6 +212,10 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
     (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 2, 3),
     (3, 7, 768, 512, [40], "float32", 2, 3),
     (3, 7, 768, 512, [40], "float64", 0, 3),
+    (4, 17, 2048, 512, [33, 18], "float32", 2, 4),
+    (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 2, 4),
+    (3, 9, 768, 512, [40], "float64", 0, 4),
+    (2, 3, 512, 256, [9], "float32", 2, 4),              # halo 3: never four exact ghost columns -> shorter passes and single steps
     (4, 17, 2048, 512, [33, 18], "float32", 2, 3),
     (2, 2, 512, 256, [9], "float32", 2, 3),              # halo 2: never three exact ghost columns -> single steps only
     (8, 16, 4096, 256, [50], "float32", 0, 0),           # automatic choice
