@@ -61,13 +61,16 @@ def main():
     fe, wr = counters(fetch_db), counters(write_db)
     march = "_march" in key
     march3 = key.endswith("_march3")
+    march4 = key.endswith("_march4")
     rows = []
     fetch_kb = write_kb = 0.0
     for k in sorted(set(fe) | set(wr)):
         f = fe.get(k, {}).get("FETCH_SIZE")
         wv = wr.get(k, {}).get("WRITE_SIZE")
         rows.append([k, f, wv])
-        if march3:
+        if march4:
+            use = ((k.startswith("wt::k_march3<") and ",4,false," in k) or k.startswith("wt::k_halo4<"))
+        elif march3:
             use = ((k.startswith("wt::k_march3<") and ",3,false," in k) or k.startswith("wt::k_halo3<"))
         elif march:
             use = ((k.startswith("wt::k_march<") and ",false," in k) or k.startswith("wt::k_halo_from_seams"))
@@ -87,7 +90,8 @@ def main():
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[key] = {
         "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
-        "kernel": ("one pass = wt::k_halo3 + wt::k_march3<3,false,FD> (THREE steps)" if march3 else
+        "kernel": ("one pass = wt::k_halo4 + wt::k_march3<T,S,4,false,FD> (FOUR steps)" if march4 else
+                   "one pass = wt::k_halo3 + wt::k_march3<T,S,3,false,FD> (THREE steps)" if march3 else
                    "one pass = wt::k_halo_from_seams + wt::k_march<T,S,false,FD> (TWO steps)" if march else "wt::k_step<float,false,...> (non-emitting step)"),
         "measured": datetime.date.today().isoformat() + ", rocprofv3 --pmc on one MI355X box of the gpurun pool, `python bench.py` default workload, "
                     "separate passes for FETCH_SIZE and WRITE_SIZE (not the run that prints the bench line)",
