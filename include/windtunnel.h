@@ -88,8 +88,9 @@ const char *wt_version(void);
  *       csrc/step_march3.hpp: three); results are bit-identical either way.  fp32 and fp64 handles (whole lattices and slabs) with an even NY, at least 8 local
  *       columns and a lattice below 4 GiB.  Default: 1 (environment WT_FUSE2=0|1|2 overrides at wt_create); handles
  *       that are not eligible, or too small for it to pay, stay on the single-step kernel.
- *   "fuse_depth" (0 = automatic / 2 / 3): steps per pass.  Default 3 where it pays (fp32: 2 sites per lane, fp64: 1; needs 16
- *       local columns).  A step count that is not a multiple is finished with a shorter pass or single steps.
+ *   "fuse_depth" (0 = automatic / 2 / 3 / 4): steps per pass.  Default 3 where it pays, 4 on lattices with long units (fp32: 2
+ *       sites per lane, fp64: 1; needs 16 local columns).  A step count that is not a multiple is finished with shorter passes
+ *       or single steps.
  *   "fuse_sites" (0 = automatic / 2 / 4): sites per lane of the two-step marching kernel = window height / 64.  fp64 handles
  *       use 2; fp32 handles 4 (256-row windows) on wide lattices and 2 (128-row windows, twice the units) on narrow
  *       ones such as column slabs; 4 needs NY % 4 == 0.
