@@ -1,4 +1,4 @@
-// step_march3.hpp — THREE lattice steps per pass: 8-byte vectors per lane and direction —
+// step_march3.hpp — THREE or FOUR lattice steps per pass: 8-byte vectors per lane and direction —
 //   <float, 2>  fp32, 2 sites per lane, 128-row windows (the fp32 default);
 //   <double, 1> fp64, 1 site per lane, 64-row windows.
 // Below, "128 rows" stands for WIN = 64 * S.
@@ -6,18 +6,18 @@
 // Why: the SQ counters of the two-step kernel (profiles/r02_c_sq_counters.txt) show its vector-memory issue stalled on a
 // full texture-addresser command FIFO for about as many cycles as the kernel runs, with the vector ALU 30 % busy — it is
 // bound by the per-CU load/store path (~10 B/clk/CU of L1-miss traffic, the same limit k_step sits on), not by
-// arithmetic.  The only lever left is bytes per step: a pass that advances T steps moves 9 (L + 2(T-1))/L + 9 words
-// per site instead of 18 T.  T = 3 needs one more level of register-resident intermediate columns (21 vectors); with 2
-// sites per lane that fits the 256-VGPR budget of two waves per SIMD (T = 3 with 4 sites per lane, or T = 4, does not).
+// arithmetic.  The lever left is bytes per step: a pass that advances T steps moves 9 (L + 2(T-1))/L + 9 words
+// per site instead of 18 T.  Every further level costs 21 register-resident vectors; with 8-byte vectors T = 3 takes
+// 196-225 VGPRs and T = 4 216-256 (two waves per SIMD either way; 16-byte vectors do not fit beyond T = 2).
 //
-// Pipeline of one wave (window w, columns [ia, ib)), iteration x:
+// Pipeline of one wave (window w, columns [ia, ib)), iteration x (DEPTH = 3; DEPTH = 4: one more level, march_unit4):
 //     level 1 of column x      <- STEP_FS on the nine streamed vectors of column x        (march_step1, as in the two-step kernel)
 //     level 2 of column x - 1  <- STEP_FS on level 1 of columns x-2, x-1, x               (march_stage)
 //     level 3 of column x - 2  <- STEP_FS on level 2 of columns x-3, x-2, x-1 -> stored   (march_stage)
-// The rows just outside the window come from two halo tables per pass: H1 (level-1 values) and H2 (level-2 values),
-// built by k_halo3 from the seam buffer S3 the previous pass wrote (four rows on either side of every seam) or, when
+// The rows just outside the window come from one halo table per level below the last (H1: level-1 values, H2, H3), built per
+// pass by k_halo3 / k_halo4 from the seam buffer S3 the previous pass wrote (four rows on either side of every seam) or, when
 // that is stale, from the lattice.
-// Every site goes through the arithmetic of k_step three times: results are bit-identical to three single steps.
+// Every site goes through the arithmetic of k_step DEPTH times: results are bit-identical to DEPTH single steps.
 #pragma once
 #include "step_march.hpp"
 
