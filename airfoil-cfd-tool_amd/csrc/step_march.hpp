@@ -65,7 +65,7 @@ static inline int march_nwin(int ny, int win) { return (ny + win - 1) / win; }
 template <typename T, int FD>
 __device__ __forceinline__ void collide_t(const T (&fin)[9], const FastDiv &fdv, T tau, T (&fo)[9], T &rho, T &ux, T &uy)
 {
-    if constexpr (sizeof(T) == 4) collide_fd<FD>(fin, fdv, fo, rho, ux, uy);
+    if constexpr (sizeof(T) == 4) collide_fd<(FD & 3)>(fin, fdv, fo, rho, ux, uy);
     else collide<T>(fin, tau, fo, rho, ux, uy);
 }
 
@@ -437,12 +437,83 @@ template <int S> __device__ __forceinline__ uint32_t load_site_bytes(const uint8
     else return *p;
 }
 
+// Two fp32 sites per lane as 2-vectors: the operations of collide_head / collide_tail (d2q9.hpp), element for element, written
+// on float2 so that hipcc emits packed instructions (v_pk_add / v_pk_mul / v_pk_fma_f32) without the register-shuffling moves
+// its SLP vectoriser pays for the same pairs (a third of the loop's vector instructions go away).  Selected by bit 2 of FD
+// (MARCH_FD_PACKED): measured in alternating runs on one box it gains 3.4 % in the four-step kernel (158 -> 163 GLUPS), which
+// is bound by its instruction stream, and loses 1-1.5 % in the three-step kernel on slab-sized lattices.
+static constexpr int MARCH_FD_PACKED = 4;
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int FD>
+__device__ __forceinline__ void collide2_packed(const f2v (&fin)[9], const FastDiv &fdv, f2v (&fo)[9], f2v &rho, f2v &ux, f2v &uy)
+{
+    f2v r, u, v;
+    moments<f2v>(fin, r, u, v);
+    const float rhoMin = 0.5f, rhoMax = 2.0f, uMax = 0.35f;        // html:344
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float ri = r[i];
+        ri = (ri < rhoMin) ? rhoMin : ri;
+        ri = (rhoMax < ri) ? rhoMax : ri;
+        r[i] = ri;
+    }
+    const f2v spd2 = u * u + v * v;
+    bool safe = true;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[0][i]), __builtin_fabsf(fin[1][i])), __builtin_fabsf(fin[2][i]));
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[3][i]), __builtin_fabsf(fin[4][i])), __builtin_fabsf(fin[5][i]));
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(fin[6][i]), __builtin_fabsf(fin[7][i])), __builtin_fabsf(fin[8][i]));
+        const float m = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2);
+        safe = safe && (m < 0x1p100f) && (r[i] == r[i]) && (spd2[i] == spd2[i]);
+    }
+    const bool fast = (FD == 2) || (FD == 1 && __ballot(!safe) == 0ULL);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        if (spd2[i] > uMax * uMax) {
+            const float k = uMax / wt_sqrt<float>(spd2[i]);
+            u[i] *= k;
+            v[i] *= k;
+        }
+    }
+    f2v eq[9];
+    feq_all<f2v>(r, u, v, eq);
+    if (FD != 0 && fast) {
+        const f2v rt = {fdv.rtau, fdv.rtau}, ta = {fdv.tau, fdv.tau};
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const f2v x = fin[k] - eq[k];
+            const f2v q0 = x * rt;
+            const f2v e = __builtin_elementwise_fma(-q0, ta, x);
+            fo[k] = fin[k] - __builtin_elementwise_fma(e, rt, q0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const f2v x = fin[k] - eq[k];
+            f2v q;
+            q[0] = x[0] / fdv.tau; q[1] = x[1] / fdv.tau;
+            fo[k] = fin[k] - q;
+        }
+    }
+    rho = r; ux = u; uy = v;
+}
+
 // collide S sites per lane; fp32: one wave-uniform decision between the fast and the IEEE division by tau
 template <typename T, int S, int FD>
 __device__ __forceinline__ void march_collide_sites(const MV<T, S> (&fin)[9], const FastDiv &fdv, T tau, MV<T, S> (&o)[9], MV<T, S> &rho4, MV<T, S> &ux4,
                                                     MV<T, S> &uy4)
 {
-    if constexpr (sizeof(T) == 4) {
+    constexpr int FDV = FD & 3;          // how to divide by tau (d2q9.hpp)
+    if constexpr (sizeof(T) == 4 && S == 2 && (FD & MARCH_FD_PACKED) != 0) {
+        f2v a[9], f[9], r, u, w;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = f2v{fin[k].v[0], fin[k].v[1]};
+        collide2_packed<FDV>(a, fdv, f, r, u, w);
+#pragma unroll
+        for (int k = 0; k < 9; k++) { o[k].v[0] = f[k][0]; o[k].v[1] = f[k][1]; }
+        rho4.v[0] = r[0]; rho4.v[1] = r[1]; ux4.v[0] = u[0]; ux4.v[1] = u[1]; uy4.v[0] = w[0]; uy4.v[1] = w[1];
+    } else if constexpr (sizeof(T) == 4) {
         float r[S], u[S], w[S], s2[S];
         bool safe = true;
 #pragma unroll
@@ -454,13 +525,13 @@ __device__ __forceinline__ void march_collide_sites(const MV<T, S> (&fin)[9], co
             collide_head(a, r[v], u[v], w[v], s2[v], sv);
             safe = safe && sv;
         }
-        const bool fast = (FD == 2) || (FD == 1 && __ballot(!safe) == 0ULL);
+        const bool fast = (FDV == 2) || (FDV == 1 && __ballot(!safe) == 0ULL);
 #pragma unroll
         for (int v = 0; v < S; v++) {
             float a[9], f[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
-            if (FD != 0 && fast) collide_tail<true>(a, fdv, r[v], u[v], w[v], s2[v], f);
+            if (FDV != 0 && fast) collide_tail<true>(a, fdv, r[v], u[v], w[v], s2[v], f);
             else collide_tail<false>(a, fdv, r[v], u[v], w[v], s2[v], f);
 #pragma unroll
             for (int k = 0; k < 9; k++) o[k].v[v] = f[k];

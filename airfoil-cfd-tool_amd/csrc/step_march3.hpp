@@ -807,8 +807,9 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     }
     const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= PAD + 1 && ib + g.gi0 <= g.nx_g - PAD - 1 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
     if (DEPTH == 4) {
-        if (lean) march_unit4<false, EMIT, FD, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
-        else march_unit4<true, EMIT, FD, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+        constexpr int FDP = sizeof(T) == 4 ? (FD | MARCH_FD_PACKED) : FD;     // fp32: the packed two-site collision (step_march.hpp)
+        if (lean) march_unit4<false, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit4<true, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     } else if (DEPTH == 3) {
         if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
         else march_unit3<true, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
