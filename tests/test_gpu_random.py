@@ -56,3 +56,35 @@ def test_random_case(pkg, oracle_c, seed):
             f, m = e.read_f(), e.read_macro()
         assert bits_equal(f, ref_f), (seed, fuse, depth, nx, ny, dtype)
         assert all(bits_equal(a, b) for a, b in zip(m, ref_m)), (seed, fuse)
+
+
+@pytest.mark.parametrize("dtype,nx,ny", [("float32", 1500, 1280), ("float64", 1300, 768)])
+def test_random_large_default_plan(pkg, oracle_c, dtype, nx, ny):
+    """A lattice large enough for the AUTOMATIC plan (several rounds of long units, many windows), speckles + blocks + lines on the
+    seams of 64-, 128- and 256-row windows and on both tunnel ends; default options, then every depth forced; uneven step counts."""
+    rng = np.random.default_rng(4242)
+    m = np.zeros((ny, nx), np.uint8)
+    m[rng.random((ny, nx)) < 0.0015] = 1
+    for r in (63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 511, 512, 513):
+        if r < ny:
+            x0 = int(rng.integers(0, nx - 60))
+            m[r, x0:x0 + int(rng.integers(1, 60))] = 1
+    for _ in range(5):
+        x0, y0 = int(rng.integers(0, nx)), int(rng.integers(0, ny))
+        m[y0:y0 + int(rng.integers(2, 90)), x0:x0 + int(rng.integers(2, 120))] = 1
+    m[ny // 3: ny // 3 + 40, 0:3] = 1; m[ny // 2: ny // 2 + 30, nx - 3:nx] = 1; m[0, 100:140] = 1; m[ny - 1, 300:350] = 1
+    steps = [4, 3, 7, 1, 6]
+    tau, u0 = 0.56, 0.07
+    ref_f, ref_m = oracle_c.run(m, sum(steps), tau, u0, np.dtype(dtype))
+    for depth in (0, 2, 3, 4):
+        with pkg.Engine(nx, ny, dtype=dtype) as e:
+            if depth:
+                e.set_option("fuse_depth", depth)
+                e.set_option("fuse_steps", 2)
+            e.set_mask(m); e.init_equilibrium(u0)
+            assert depth == 0 or e.get_option("fuse_active") == 1.0
+            for n in steps:
+                e.step(n, tau, u0)
+            f, mac = e.read_f(), e.read_macro()
+        assert bits_equal(f, ref_f), (dtype, depth)
+        assert all(bits_equal(a, b) for a, b in zip(mac, ref_m)), (dtype, depth)
