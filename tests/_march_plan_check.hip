@@ -1,0 +1,63 @@
+// Host-only check of build_march_plan (csrc/step_march.hpp): compiled by tests/test_march_plan.py with hipcc and run on the CPU —
+// it makes no HIP runtime call.  Invariants: every marched column of every window belongs to exactly one unit, units respect
+// the length cap and the minimum length of a window's last unit, the outlet flag sits on the last unit only, and with a target
+// the unit count does not exceed it (whole resident rounds).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+#include "../airfoil-cfd-tool_amd/csrc/step_march3.hpp"
+using namespace wt;
+
+static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, int depth, long target, int max_cost, unsigned seed)
+{
+    Geom g{};
+    g.nxl = nxl; g.ny = ny; g.gi0 = gi0; g.nx_g = nx_g; g.pitch = (ny + 255) / 256 * 256; g.plane = (long)(nxl + 2) * g.pitch + 4352;
+    const int nwin = march_nwin(ny, win), ld = nxl + 2;
+    std::vector<uint8_t> wcls((size_t)nwin * ld, WC_FAST);
+    std::mt19937 rng(seed);
+    for (int w = 0; w < nwin; w++)
+        for (int x = 0; x < nxl; x++) { const unsigned r = rng() % 100; if (r < 6) wcls[(size_t)w * ld + x + 1] = r < 2 ? WC_SOLID : WC_GENERAL; }
+    const MarchRange r = depth >= 3 ? march_range3(g, depth) : march_range(g);
+    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
+    const MarchPlan pl = build_march_plan(wcls.data(), g, win, target, max_cost, 2.0, &r, min_last, max_len);
+    int bad = 0;
+    std::vector<int> cover((size_t)nwin * nxl, 0);
+    std::vector<int> last_len(nwin, -1), n_outlet(nwin, 0);
+    for (const MarchUnit &u : pl.units) {
+        if (u.w < 0 || u.w >= nwin || u.ia < r.i_begin || u.ib > r.i_end || u.ib <= u.ia) { bad++; continue; }
+        if (u.ib - u.ia > max_len + min_last - 1) bad++;      // a suppressed cut before a short last unit may add min_last - 1 columns
+        for (int x = u.ia; x < u.ib; x++) cover[(size_t)u.w * nxl + x]++;
+        if (u.ib == r.i_end) last_len[u.w] = u.ib - u.ia;
+        if (u.flags & MU_OUTLET_AFTER) { n_outlet[u.w]++; if (u.ib != r.i_end || !r.outlet_after) bad++; }
+    }
+    for (int w = 0; w < nwin; w++) {
+        for (int x = 0; x < nxl; x++) if (cover[(size_t)w * nxl + x] != ((x >= r.i_begin && x < r.i_end) ? 1 : 0)) bad++;
+        if (r.i_end - r.i_begin >= min_last && last_len[w] < min_last) bad++;
+        if (n_outlet[w] != (r.outlet_after ? 1 : 0)) bad++;
+    }
+    if (max_cost <= 0 && target >= nwin && (long)pl.units.size() > target + (long)nwin * ((r.i_end - r.i_begin) / max_len + 1)) bad++;   // cap-forced cuts aside
+    printf("%-28s nxl %5d ny %5d win %3d depth %d target %5ld max_cost %2d: %6zu units, chunk %2d  %s\n", name, nxl, ny, win, depth, target, max_cost,
+           pl.units.size(), pl.chunk, bad ? "FAIL" : "ok");
+    return bad;
+}
+
+int main()
+{
+    int bad = 0;
+    for (int depth : {2, 3, 4}) {
+        const int win = depth == 2 ? 256 : 128;
+        bad += check("whole lattice", 4096, 4096, 0, 4096, win, depth, 4096, 0, 1);
+        bad += check("whole lattice, tiny target", 512, 256, 0, 512, win, depth, 2048, 0, 2);      // one-column units
+        bad += check("whole lattice, max_cost", 512, 256, 0, 512, win, depth, 2048, 7, 3);
+        bad += check("whole lattice, max_cost 1", 300, 520, 0, 300, win, depth, 2048, 1, 4);
+        bad += check("left slab", 544, 4096, 0, 4096, win, depth, 2048, 0, 5);
+        bad += check("middle slab", 544, 4096, 1760, 4096, win, depth, 2048, 0, 6);
+        bad += check("right slab", 544, 4096, 3552, 4096, win, depth, 2048, 0, 7);
+        bad += check("narrow slab", 24, 1000, 64, 4096, win, depth, 2048, 0, 8);
+        bad += check("fp64-like windows", 4096, 2048, 0, 4096, 64, depth, 6144, 0, 9);
+        bad += check("long units", 16384, 256, 0, 16384, win, depth, 16, 0, 10);                    // cap-forced cuts
+    }
+    printf("%s\n", bad ? "PLAN CHECK FAILED" : "plan check passed");
+    return bad ? 1 : 0;
+}
