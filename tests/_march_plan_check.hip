@@ -36,7 +36,7 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
         if (r.i_end - r.i_begin >= min_last && last_len[w] < min_last) bad++;
         if (n_outlet[w] != (r.outlet_after ? 1 : 0)) bad++;
     }
-    if (max_cost <= 0 && target >= nwin && (long)pl.units.size() > target + (long)nwin * ((r.i_end - r.i_begin) / max_len + 1)) bad++;   // cap-forced cuts aside
+    if (max_cost <= 0 && target >= nwin && pl.chunk < max_len && (long)pl.units.size() > target) bad++;      // whole rounds, unless the length cap forces more units
     printf("%-28s nxl %5d ny %5d win %3d depth %d target %5ld max_cost %2d: %6zu units, chunk %2d  %s\n", name, nxl, ny, win, depth, target, max_cost,
            pl.units.size(), pl.chunk, bad ? "FAIL" : "ok");
     return bad;
