@@ -23,7 +23,7 @@ WT_COMM_ID_BYTES = 128
 EXPORTS = (
     "wt_create", "wt_create_slab", "wt_destroy", "wt_get_info", "wt_last_error", "wt_version",
     "wt_set_option", "wt_get_option",
-    "wt_comm_unique_id", "wt_comm_init_rank", "wt_comm_selftest", "wt_link_local", "wt_step_group",
+    "wt_comm_unique_id", "wt_comm_init_rank", "wt_comm_selftest", "wt_link_local", "wt_step_group", "wt_step_group_timed",
     "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_read_f", "wt_write_f",
     "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_clamp_events", "wt_field", "wt_render_rgba", "wt_advect_tracers", "wt_sync",
 )
@@ -78,6 +78,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "wt_comm_selftest": ([c_int, c_int], c_int),
         "wt_link_local": ([POINTER(H), c_int], c_int),
         "wt_step_group": ([POINTER(H), c_int, c_int, c_double, c_double], c_int),
+        "wt_step_group_timed": ([POINTER(H), c_int, c_int, c_double, c_double, POINTER(c_float)], c_int),
         "wt_set_mask": ([H, c_void_p], c_int),
         "wt_init_equilibrium": ([H, c_double], c_int),
         "wt_step": ([H, c_int, c_double, c_double], c_int),
@@ -189,6 +190,14 @@ class Engine:
     def step_group(engines, nsteps: int, tau: float, u0: float) -> None:
         arr = (c_void_p * len(engines))(*[e._h for e in engines])
         _check(load_library().wt_step_group(arr, len(engines), int(nsteps), float(tau), float(u0)))
+
+    @staticmethod
+    def step_group_timed(engines, nsteps: int, tau: float, u0: float):
+        """step_group with each slab's device time (ms) from HIP events on its compute stream."""
+        arr = (c_void_p * len(engines))(*[e._h for e in engines])
+        ms = (c_float * len(engines))()
+        _check(load_library().wt_step_group_timed(arr, len(engines), int(nsteps), float(tau), float(u0), ms))
+        return [float(v) for v in ms]
 
     # -- state --
     def set_mask(self, mask: np.ndarray) -> None:

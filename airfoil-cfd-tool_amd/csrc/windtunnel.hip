@@ -99,10 +99,12 @@ struct wt_handle {
     bool fuse = false;
     int fuse_sites = 0;                  // option: sites per lane of the marching kernel (0 = automatic; 2 or 4)
     int fuse_depth = 0;                  // option: steps per pass (0 = automatic; 2 or 3)
-    int march_depth = 0;                 // steps per pass in use (3: step_march3.hpp, fp32 with 2 sites per lane)
+    int march_depth = 0;                 // steps per pass the plan's tables are built for (3 / 4: step_march3.hpp; 2: step_march.hpp)
+    int pass_cap = 0;                    // longest pass actually taken on those tables (0 = march_depth): fp64 with fuse_depth = 2
     void *halo2 = nullptr;               // depth 3 / 4: level-2 halo table
     void *halo3 = nullptr;               // depth 4: level-3 halo table
     long long passes = 0;
+    long long single_steps = 0;          // k_step launches of whole steps (option "single_steps"): what a fused plan falls back to
     long long march_table_bytes = 0;     // wcls + halo_tab + seams + seam_plain (part of device_bytes)
     int march_s = 0;                     // sites per lane in use (4: fp32 256-row windows; 2: fp64, or fp32 on narrow lattices)
     bool fuse_force = false;             // fuse_steps = 2: also when the lattice is too small for it to pay
@@ -321,10 +323,11 @@ extern "C" int wt_sync(wt_handle *h)
 static bool fuse_eligible_s(const wt_handle *h, int sites)
 {
     const unsigned long long eb = h->dtype == WT_F32 ? 4 : 8;
-    if (sites * eb != 16 && sites * eb != 8) return false;                  // 16-byte vectors (two steps per pass), 8-byte (two or three)
+    if (sites * eb != 8) return false;                                      // 8-byte vectors: fp32 with 2 sites per lane, fp64 with 1
     return h->g.ny % sites == 0 && h->g.nxl >= 8 && 9ULL * h->g.plane * eb < (1ULL << 32) - (1ULL << 20);
 }
-static bool fuse_eligible(const wt_handle *h) { return fuse_eligible_s(h, 2) || fuse_eligible_s(h, 4); }
+static bool fuse_eligible(const wt_handle *h) { return fuse_eligible_s(h, h->dtype == WT_F32 ? 2 : 1); }
+static inline int eff_depth(const wt_handle *h) { return h->pass_cap > 0 && h->pass_cap < h->march_depth ? h->pass_cap : h->march_depth; }
 
 static void free_march_tables(wt_handle *h)
 {
@@ -445,24 +448,26 @@ static long march_target_units(const wt_handle *h, int sites, long slots, bool f
     return target;
 }
 
-// Steps per pass and sites per lane.  THREE steps per pass (step_march3.hpp: fp32 with 2 sites per lane, fp64 with 1) where
-// eligible and not switched off (fuse_depth = 2); otherwise two steps per pass — fp32 with 4 sites per lane (256-row windows)
-// where that plan has enough units to pay, else 2 (128-row windows: twice the units — narrow lattices such as column slabs);
-// fp64 with 2 sites (16-byte vectors).  fuse_depth / fuse_sites override.  The choice depends on the geometry only, so a mask change
-// rebuilds the tables in place.
+// Steps per pass.  Every marching kernel holds 8-byte vectors per lane and direction (fp32: 2 sites per lane, 128-row windows; fp64: 1
+// site, 64-row windows).  THREE steps per pass (step_march3.hpp) where eligible, FOUR where the units are long; fuse_depth = 2 selects two
+// steps per pass: fp32 the two-step kernel of step_march.hpp on its own (smaller) tables — also the automatic choice for lattices too
+// narrow for three steps to pay —, fp64 two-step passes of the three-step kernel on its tables.  (Round 2 also shipped 16-byte-vector
+// instantiations of the two-step kernel — fp32 with 4 sites per lane, fp64 with 2; they spilled registers, were never the automatic
+// choice on any lattice and are gone.)  The choice depends on the geometry only, so a mask change rebuilds the tables in place.
 static int rebuild_fuse_plan(wt_handle *h)
 {
     h->fuse_ready = false;
     h->n_units = h->nonfast_tiles = 0;
+    h->pass_cap = 0;
     if (!h->fuse || !fuse_eligible(h) || !h->mask_set) return WT_OK;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, h->device));
     long waves = 2;                                                      // resident marching waves per SIMD
     if (const char *e = getenv("WT_MARCH_WAVES")) waves = atoi(e) > 0 ? atoi(e) : 2;
     const long slots = (long)prop.multiProcessorCount * 4 * waves;
-    // three steps per pass (the default where it pays): 8-byte vectors — fp32 with 2 sites per lane, fp64 with 1
     const int s3 = h->dtype == WT_F32 ? 2 : 1;
-    const bool depth3_ok = fuse_eligible_s(h, s3) && h->g.nxl >= 16 && h->fuse_depth != 2 && (h->fuse_sites == 0 || h->fuse_sites == s3);
+    const bool two_on_three = h->dtype != WT_F32 && h->fuse_depth == 2;  // fp64: two-step passes on the three-step tables
+    const bool depth3_ok = h->g.nxl >= 16 && (h->fuse_depth != 2 || two_on_three);
     if (depth3_ok) {
         // four steps per pass where the units are long (measured, same box: fp32 4096^2 154.2 -> 156.7 GLUPS, 2080 / 1056 / 544 columns
         // 63.0 -> 63.9 / 36.7 -> 37.6 / 24.7 -> 25.2 us per step; fp64 4096^2 82.4 -> 87.9 GLUPS, 4096 x 2048 72.5 -> 75.5, 1056 columns +1 %)
@@ -470,31 +475,24 @@ static int rebuild_fuse_plan(wt_handle *h)
         const int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (h->dtype == WT_F32 ? 48 : 24)) ? 4 : 3;
         const MarchRange r = march_range3(h->g, depth);
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
-        const bool force = h->fuse_force || h->fuse_depth >= 3;
+        const bool force = h->fuse_force || h->fuse_depth >= 2;
         if (force || h->fuse_chunk > 0 || tiles / slots >= 6) {
             long target = 2 * slots;
             if (tiles / target < 12) target = slots;
             while (tiles / target > MARCH_MAX_CHUNK - 6) target += slots;     // a unit holds at most MARCH_MAX_CHUNK columns: more rounds
             WT_TRY(build_fuse_plan(h, s3, target, depth));
             h->fuse_ready = h->n_units > 0;
+            h->pass_cap = two_on_three ? 2 : 0;
             return WT_OK;
         }
     }
-    if (h->fuse_depth >= 3) return WT_OK;
-    int order[2] = {4, 2}, n = 2;
-    if (h->dtype != WT_F32) { order[0] = 2; n = 1; }
-    else if (h->fuse_sites == 2 || h->fuse_sites == 4) { order[0] = h->fuse_sites; n = 1; }
-    for (int t = 0; t < n; t++) {
-        if (!fuse_eligible_s(h, order[t])) continue;
-        // automatic choice on fp32: 256-row windows only where one round of them gets 16 columns per unit (measured on
-        // 4096 rows: 2080 columns 81.0 us/step with 4 sites vs 82.5 with 2; 1056 columns 48.0 vs 43.5; 544 columns 31.1 vs
-        // 25.9 against 33.5 for single steps)
-        const long target = march_target_units(h, order[t], slots, h->fuse_force && t == n - 1, (n == 2 && t == 0) ? 16 : 4);
-        if (target == 0) continue;
-        WT_TRY(build_fuse_plan(h, order[t], target, 2));
-        h->fuse_ready = h->n_units > 0;
-        break;
-    }
+    if (h->fuse_depth >= 3 || h->dtype != WT_F32) return WT_OK;
+    // fp32, two steps per pass on 128-row windows (measured with 4096 rows: 288 columns = 4.5 per unit 16.6 us/step against 20.9 for
+    // single steps and 18.5 for three steps per pass)
+    const long target = march_target_units(h, 2, slots, h->fuse_force, 4);
+    if (target == 0) return WT_OK;
+    WT_TRY(build_fuse_plan(h, 2, target, 2));
+    h->fuse_ready = h->n_units > 0;
     return WT_OK;
 }
 
@@ -515,17 +513,18 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
     HIP_TRY(hipSetDevice(h->device));
     if (strcmp(name, "fuse_steps") == 0) {
         if (value != 0.0 && !fuse_eligible(h))
-            return fail(WT_ERR_STATE, "fuse_steps needs an even NY, at least 8 local columns and a lattice below 4 GiB");
+            return fail(WT_ERR_STATE, "fuse_steps needs at least 8 local columns, a lattice below 4 GiB and (fp32) an even NY");
         h->fuse = value != 0.0;
         h->fuse_force = value >= 2.0;
         return rebuild_fuse_plan(h);
     }
     if (strcmp(name, "fuse_sites") == 0) {
-        if (!(value == 0.0 || value == 2.0 || value == 4.0)) return fail(WT_ERR_ARG, "fuse_sites must be 0 (automatic), 2 or 4");
-        if (value != 0.0 && !fuse_eligible_s(h, (int)value))
-            return fail(WT_ERR_STATE, "fuse_sites: this handle cannot march with that many sites per lane (fp64: 2; NY must be a multiple of it)");
+        // kept for callers of round 2: the sites per lane are fixed by the element type now (see rebuild_fuse_plan)
+        const int s3 = h->dtype == WT_F32 ? 2 : 1;
+        if (!(value == 0.0 || value == (double)s3))
+            return fail(WT_ERR_ARG, "fuse_sites must be 0 (automatic) or %d for this handle (the 16-byte-vector kernels of round 2 are gone)", s3);
         h->fuse_sites = (int)value;
-        return rebuild_fuse_plan(h);
+        return WT_OK;
     }
     if (strcmp(name, "fuse_depth") == 0) {
         if (!(value == 0.0 || value == 2.0 || value == 3.0 || value == 4.0)) return fail(WT_ERR_ARG, "fuse_depth must be 0 (automatic), 2, 3 or 4");
@@ -555,9 +554,11 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_ready ? h->fuse_chunk_used : h->fuse_chunk; return WT_OK; }
     if (strcmp(name, "fuse_units") == 0) { *value = h->n_units; return WT_OK; }
     if (strcmp(name, "fuse_sites") == 0) { *value = h->fuse_ready ? h->march_s : h->fuse_sites; return WT_OK; }
-    if (strcmp(name, "fuse_depth") == 0) { *value = h->fuse_ready ? h->march_depth : h->fuse_depth; return WT_OK; }
+    if (strcmp(name, "fuse_depth") == 0) { *value = h->fuse_ready ? eff_depth(h) : h->fuse_depth; return WT_OK; }
     if (strcmp(name, "fuse_tiles_general") == 0) { *value = h->nonfast_tiles; return WT_OK; }   // window-tiles that take the body paths
     if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "single_steps") == 0) { *value = (double)h->single_steps; return WT_OK; }   // whole steps taken by k_step since the last init / write_f
+    if (strcmp(name, "passes") == 0) { *value = (double)h->passes; return WT_OK; }
     if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
@@ -641,6 +642,7 @@ extern "C" int wt_init_equilibrium(wt_handle *h, double u0)
     h->macro_stale = false;
     h->seams_valid = false;
     h->steps_done = 0;
+    h->single_steps = 0;
     h->ghost_valid = h->halo;     // a uniform state is exact everywhere, ghosts included
     return WT_OK;
 }
@@ -763,6 +765,7 @@ static int step_compute(wt_handle *h, double tau, double u0, bool emit, bool ref
     }
     h->cur = 1 - h->cur;
     h->steps_done += 1;
+    h->single_steps += 1;
     h->seams_valid = false;
     return WT_OK;
 }
@@ -844,6 +847,7 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
     HIP_TRY(hipGetLastError());
     h->cur = 1 - h->cur;
     h->steps_done += 2;
+    h->passes += 1;
     h->seams_valid = true;                       // the pass wrote the seam rows of the lattice it produced
     if (h->nranks > 1) h->ghost_valid -= 2;      // two columns of ghost validity consumed
     return WT_OK;
@@ -851,10 +855,9 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
 
 static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
 {
-    if (h->dtype != WT_F32) return step_pair_fused_t<double, 2, 0>(h, tau, u0, emit);
+    if (h->dtype != WT_F32 || h->march_s != 2) return fail(WT_ERR_STATE, "internal: the two-step kernel runs fp32 handles with 2 sites per lane only");
     bool fd = false;
     WT_TRY(fastdiv_for(h, (float)tau, &fd));
-    if (h->march_s == 4) return fd ? step_pair_fused_t<float, 4, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 4, 0>(h, tau, u0, emit);
     return fd ? step_pair_fused_t<float, 2, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 2, 0>(h, tau, u0, emit);
 }
 
@@ -914,15 +917,25 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     return WT_OK;
 }
 
-// steps the next fused pass can advance given `left` steps to go (0: none — take a single step).  A pass needs as many exact
-// ghost columns as it advances steps; the three-step plan also runs two-step passes on its tables.
+// Steps the next fused pass advances given `left` steps to go (0: none — take a single step).  A pass needs as many exact ghost
+// columns as it advances steps.  The tables of a depth-D plan also run every shorter pass down to two steps, and a remainder of
+// ONE step is never left behind where two fused passes fit (5 = 3 + 2 on a four-step plan, 4 = 2 + 2 on a three-step plan): a
+// single k_step clears the seam buffer, and the next pass would then build its halo tables by the gather path.
+static inline int fuse_pick(int depth, int avail)
+{
+    if (avail < 2) return 0;
+    if (depth <= 2) return 2;                                   // the two-step kernel (step_march.hpp) has no shorter pass
+    if (avail >= depth) return (avail - depth == 1) ? depth - 1 : depth;
+    return avail;
+}
+static inline int fuse_avail(const wt_handle *h, int left)
+{
+    return h->nranks == 1 ? left : (left < h->ghost_valid ? left : h->ghost_valid);
+}
 static inline int fuse_stride(const wt_handle *h, int left)
 {
     if (!h->fuse_ready) return 0;
-    const int avail = h->nranks == 1 ? left : (left < h->ghost_valid ? left : h->ghost_valid);
-    if (h->march_depth == 4) return avail >= 4 ? 4 : (avail >= 2 ? avail : 0);
-    if (h->march_depth == 3) return avail >= 3 ? 3 : (avail >= 2 ? 2 : 0);
-    return avail >= 2 ? 2 : 0;
+    return fuse_pick(eff_depth(h), fuse_avail(h, left));
 }
 
 static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
@@ -1088,9 +1101,17 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
     }
     int s = 0;
     while (s < nsteps) {
-        const int k = fuse_stride(hs[0], nsteps - s);
-        bool fused = k > 0;
-        for (int r = 0; r < n && fused; r++) fused = fuse_stride(hs[r], nsteps - s) == k;
+        // one pass length for the whole group: the shortest plan depth and the fewest exact ghost columns of any slab (edge
+        // slabs are narrower than interior ones and may have chosen another depth; a depth-4 table also runs 2- and 3-step passes)
+        int depth = 1 << 30, avail = nsteps - s;
+        bool fused = true;
+        for (int r = 0; r < n && fused; r++) {
+            fused = hs[r]->fuse_ready;
+            depth = std::min(depth, eff_depth(hs[r]));
+            avail = std::min(avail, fuse_avail(hs[r], nsteps - s));
+        }
+        const int k = fused ? fuse_pick(depth, avail) : 0;
+        fused = k > 0;
         if (fused) {                                  // k steps per pass on every slab; no exchange involved
             for (int r = 0; r < n; r++) {
                 HIP_TRY(hipSetDevice(hs[r]->device));
@@ -1134,6 +1155,28 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
         s += 1;
     }
     if (nsteps > 0) for (int r = 0; r < n; r++) hs[r]->macro_stale = false;
+    return WT_OK;
+}
+
+extern "C" int wt_step_group_timed(wt_handle **hs, int n, int nsteps, double tau, double u0, float *elapsed_ms)
+{
+    if (!hs || n < 1) return fail(WT_ERR_ARG, "no handles");
+    if (!elapsed_ms) return fail(WT_ERR_ARG, "elapsed_ms is null");
+    for (int r = 0; r < n; r++) {
+        WT_TRY(check_handle(hs[r]));
+        HIP_TRY(hipSetDevice(hs[r]->device));
+        HIP_TRY(hipEventRecord(hs[r]->ev_a, hs[r]->s_compute));
+    }
+    WT_TRY(wt_step_group(hs, n, nsteps, tau, u0));
+    for (int r = 0; r < n; r++) {
+        HIP_TRY(hipSetDevice(hs[r]->device));
+        HIP_TRY(hipEventRecord(hs[r]->ev_b, hs[r]->s_compute));
+    }
+    for (int r = 0; r < n; r++) {
+        HIP_TRY(hipSetDevice(hs[r]->device));
+        HIP_TRY(hipEventSynchronize(hs[r]->ev_b));
+        HIP_TRY(hipEventElapsedTime(&elapsed_ms[r], hs[r]->ev_a, hs[r]->ev_b));
+    }
     return WT_OK;
 }
 
@@ -1206,6 +1249,7 @@ extern "C" int wt_write_f(wt_handle *h, const void *f_in)
     h->macro_stale = true;   // the macro planes still hold the previous state's (rho,ux,uy)
     h->ghost_valid = 0;      // ghosts must be refreshed from the neighbours before the next step
     h->steps_done = 0;
+    h->single_steps = 0;
     return WT_OK;
 }
 

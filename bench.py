@@ -58,6 +58,13 @@ def parse_args():
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--shape", default="naca6409")
+    ap.add_argument("--dat", default=None, metavar="PATH",
+                    help="airfoil coordinates from a .dat file (Selig / Lednicer, parsed and repaired like the reference's back end: "
+                         "datfile.load_dat) in place of --shape; e.g. the S1223 file BASELINE configs[2] names, which neither the reference "
+                         "(.gitignore:4 excludes *.dat) nor this image ships")
+    ap.add_argument("--local-slabs", type=int, default=0, metavar="P",
+                    help="ONE process, P column slabs of the lattice as P handles on device 0 (wt_link_local + wt_step_group: the slab state "
+                         "machine and the refresh / interior overlap of the N-GPU path, run on one GPU); prints per-slab device times")
     ap.add_argument("--aoa", type=float, default=10.0)
     ap.add_argument("--u0", type=float, default=0.06)
     ap.add_argument("--tau", type=float, default=0.58)
@@ -171,6 +178,77 @@ def roofline_entry(kernel, bytes_alg, launch_ms, traffic):
     return out
 
 
+def workload_name(args, nx_total, ny, body_name):
+    note = ("coordinates from the file named" if args.dat else
+            "BASELINE configs[2]; S1223 coordinates unavailable offline -> NACA 6409; pass --dat PATH to use a supplied file"
+            if args.shape == "naca6409" else "built-in shape")
+    return f"{body_name} {nx_total}x{ny} {args.dtype} D2Q9, AoA={args.aoa:g} deg, U0={args.u0:g}, tau={args.tau:g} ({note})"
+
+
+def local_slabs_main(args, wtpkg, mask, body_name):
+    """--local-slabs P: the column-slab path of `--gpus P` with every slab on device 0 (in-process transport: peer copies on each
+    slab's comm stream in place of RCCL send/recv; every other line of the slab state machine is shared, csrc/windtunnel.hip
+    halo_begin / step_compute).  What it shows on one GPU: the refresh step's copies run beside the interior kernel (profile with
+    rocprofv3 --kernel-trace --memory-copy-trace), and what P slab-sized handles cost next to one whole lattice."""
+    import torch
+    P, ny, nx = args.local_slabs, args.ny, args.nx
+    torch.cuda.set_device(0)
+    es = [wtpkg.Engine(nx, ny, dtype=args.dtype, device=0, rank=r, nranks=P, halo=args.halo) for r in range(P)]
+    try:
+        wtpkg.Engine.link_local(es)
+        for e in es:
+            if args.fuse_chunk > 0:
+                e.set_option("fuse_chunk", args.fuse_chunk)
+            if args.fuse_depth > 0:
+                e.set_option("fuse_depth", args.fuse_depth)
+            if args.fuse >= 0:
+                e.set_option("fuse_steps", args.fuse)
+            e.set_mask(mask)
+            e.init_equilibrium(args.u0)
+        if args.warmup > 0:
+            wtpkg.Engine.step_group(es, args.warmup, args.tau, args.u0)
+        for e in es:
+            e.sync()
+        t0 = time.perf_counter()
+        dev_ms = wtpkg.Engine.step_group_timed(es, args.steps, args.tau, args.u0)
+        for e in es:
+            e.sync()
+        wall = time.perf_counter() - t0
+        # one slab handle of the same size alone on the GPU, for the "P x one slab" comparison
+        solo_ms = None
+        if P > 1:
+            w = es[1].info().width + (2 if P > 2 else 1) * args.halo
+            with wtpkg.Engine(w, ny, dtype=args.dtype, device=0) as solo:
+                if args.fuse_depth > 0:
+                    solo.set_option("fuse_depth", args.fuse_depth)
+                if args.fuse >= 0:
+                    solo.set_option("fuse_steps", args.fuse)
+                solo.set_mask(mask[:, :w].copy())
+                solo.init_equilibrium(args.u0)
+                solo.step(args.warmup, args.tau, args.u0)
+                solo_ms = solo.step_timed(args.steps, args.tau, args.u0) / args.steps
+        out = {
+            "metric": baseline_metric(), "value": nx * ny * args.steps / wall / 1e6, "unit": "MLUPS", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
+            "config": {"workload": workload_name(args, nx, ny, body_name) + f" as {P} LOCAL column slabs on one GPU", "nx": nx, "ny": ny,
+                       "slabs": P, "halo": args.halo, "transport": "local (hipMemcpyPeerAsync on each slab's comm stream)",
+                       "fuse_depth": [int(e.get_option("fuse_depth")) if e.get_option("fuse_active") else 0 for e in es],
+                       "single_steps": [int(e.get_option("single_steps")) for e in es]},
+            "local_slabs": {"device_ms_per_step": [m / args.steps for m in dev_ms], "sum_device_ms_per_step": sum(dev_ms) / args.steps,
+                            "group_wall_ms_per_step": wall / args.steps * 1e3,
+                            "one_slab_alone_ms_per_step": solo_ms,
+                            "P_times_one_slab_ms_per_step": None if solo_ms is None else P * solo_ms,
+                            "note": "per-slab device time = HIP events on that slab's compute stream around the whole timed region; the slabs share "
+                                    "one GPU, so their kernels interleave and each slab's time includes waiting for the others"},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(out), flush=True)
+    finally:
+        for e in es:
+            e.close()
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,8 +290,16 @@ def main():
 
     nx_total = args.nx if (args.scaling == "strong" or world == 1) else args.nx * world
     ny = args.ny
-    geom = wtpkg.geometry.build_geometry(nx_total, ny, args.aoa, None, args.shape)
+    user_coords, body_name = None, args.shape.upper()
+    if args.dat:
+        from airfoil_cfd_tool_amd.datfile import load_dat
+        pts, fixes = load_dat(args.dat)                       # main.py:59-180 semantics (repairs included)
+        user_coords = wtpkg.geometry.round_coords(pts)        # AA.py:34-36
+        body_name = f"{os.path.basename(args.dat)} ({len(user_coords)} points" + (f", {len(fixes)} parser repairs" if fixes else "") + ")"
+    geom = wtpkg.geometry.build_geometry(nx_total, ny, args.aoa, user_coords, args.shape)
     mask = geom.mask
+    if args.local_slabs > 0:
+        return local_slabs_main(args, wtpkg, mask, body_name)
 
     try:
         if distributed:
@@ -289,21 +375,28 @@ def main():
         main_kernel = "wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)"
     traffic = None if distributed else measured_traffic(key + (("_march4" if steps_per_launch == 4 else "_march3" if steps_per_launch == 3 else "_march") if fused else ""))
     r = roofline_entry(main_kernel, bpl * sites_per_launch * steps_per_launch, launch_ms, traffic)
-    # `achieved` is the REAL HBM rate (counters) when this workload has been profiled, else the effective rate
-    basis = "counters" if r["counter_gbps"] is not None else "effective"
-    achieved = r["counter_gbps"] if r["counter_gbps"] is not None else r["effective_gbps"]
+    # `achieved` / `frac` are the REAL HBM rate (rocprofv3 counters of this workload, profiles/pmc_traffic.json) over this run's launch time,
+    # or null when this workload was never profiled — never the "effective" figure, which a multi-step pass can push beyond the peak.
+    # Beside it: `compulsory_*` = one lattice read + one lattice write per PASS (what any T-step pass must move) and `effective_*` =
+    # 72 (144) B per site UPDATE, the throughput unit of SURVEY 8d.
+    achieved = r["counter_gbps"]
+    compulsory = bpl * sites_per_launch / (launch_ms * 1e-3) / 1e9
     cfg_fuse = {"fuse_steps": int(fused), "fuse_chunk": int(eng.get_option("fuse_chunk")) if fused else 0,
                 "fuse_units": int(eng.get_option("fuse_units")) if fused else 0,
                 "fuse_sites": int(eng.get_option("fuse_sites")) if fused else 0,
                 "fuse_depth": steps_per_launch if fused else 0,
-                "fast_div": int(eng.get_option("fast_div_active")) if fused else 0}
-    roofline = {"bound": "hbm", "kernel": main_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
+                "fast_div": int(eng.get_option("fast_div_active")) if fused else 0,
+                "single_steps": int(eng.get_option("single_steps"))}
+    # what the SQ counters say limits the kernel (profiles/r03_a_sq_counters_bench_kernel.txt): the marching kernels keep the vector ALU
+    # busy for 60-70 % of their run time with two waves per SIMD while moving 45-50 % of the HBM peak; k_step is HBM-bound.
+    roofline = {"bound": "valu" if fused else "hbm", "kernel": main_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": None if achieved is None else achieved / HBM_PEAK_GBPS,
+                "bound_note": ("vector-instruction issue (SQ_ACTIVE_INST_VALU ~ 65 % of the SIMD time at 2 waves per SIMD); the HBM figures "
+                               "say how far below the memory roof that leaves the kernel" if fused else "HBM bandwidth"),
                 "achieved_basis": ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/pmc_traffic.json) / this run's launch time"
-                                   if basis == "counters" else
-                                   f"effective: {bpl} B per site update x sites x steps per launch / launch time"
-                                   + (" (a multi-step pass moves fewer bytes than that; no counter entry for this workload)" if fused else "")),
+                                   if achieved is not None else "no counter entry for this workload in profiles/pmc_traffic.json"),
                 "traffic": r["traffic"], "traffic_source": r["traffic_source"], "counter_gbps": r["counter_gbps"],
+                "compulsory_gbps": compulsory, "compulsory_frac": compulsory / HBM_PEAK_GBPS,
                 "effective_gbps": r["effective_gbps"], "effective_frac": r["effective_frac"],
                 "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "launch_ms": launch_ms,
                 "steps_per_launch": steps_per_launch}
@@ -315,15 +408,14 @@ def main():
             n1 = max(10, min(40, args.steps))
             ms1 = eng.step_timed(n1, args.tau, args.u0) / n1
             s = roofline_entry("wt::k_step (one step per launch)", bpl * sites_per_launch, ms1, measured_traffic(key))
-            s["achieved"] = s["counter_gbps"] if s["counter_gbps"] is not None else s["effective_gbps"]
-            s["frac"] = s["achieved"] / HBM_PEAK_GBPS
+            s["achieved"] = s["counter_gbps"]                 # one step per launch: effective == compulsory
+            s["frac"] = None if s["achieved"] is None else s["achieved"] / HBM_PEAK_GBPS
             s["mlups"] = sites / (ms1 * 1e-3) / 1e6
             roofline["single_step"] = s
         except Exception as e:      # noqa: BLE001
             roofline["single_step"] = {"error": str(e)}
 
-    workload = (f"{args.shape.upper()} {nx_total}x{ny} {args.dtype} D2Q9, AoA={args.aoa:g} deg, U0={args.u0:g}, "
-                f"tau={args.tau:g} (BASELINE configs[2]; S1223 coordinates unavailable offline -> NACA 6409)")
+    workload = workload_name(args, nx_total, ny, body_name)
     out = {
         "metric": baseline_metric(),
         "value": mlups,

@@ -122,6 +122,9 @@ int wt_comm_selftest(int device, int ny);
  * wt_step_group, which advances every slab in lock-step. */
 int wt_link_local(wt_handle **hs, int n);
 int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, double u0);
+/* As wt_step_group, every slab's share bracketed by HIP events on that slab's compute stream; blocks, and returns the
+ * elapsed device time of each slab in milliseconds (elapsed_ms[n]).  Measurement only (bench.py --local-slabs). */
+int wt_step_group_timed(wt_handle **hs, int n, int nsteps, double tau, double u0, float *elapsed_ms);
 
 /* ---- state ------------------------------------------------------------------ */
 

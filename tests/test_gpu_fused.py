@@ -1,9 +1,9 @@
 """GPU: the two-steps-per-launch mode (csrc/step_march.hpp) must be bit-identical to the ordinary
 single-step path and to the oracle: plain units (register-resident step 1 -> step 2), body units
 (window-tile classes, bounce codes, inlet / outlet columns inside the march), odd/even step counts,
-macro emission, mask changes, chunk sizes, the proved fast division by tau and its IEEE fallback; all three
-instantiations — fp32 with 4 sites per lane (256-row windows), fp32 with 2 (128-row windows, narrow lattices) and
-fp64 with 2."""
+macro emission, mask changes, chunk sizes, the proved fast division by tau and its IEEE fallback; every
+kernel form — fp32 (2 sites per lane, 128-row windows) and fp64 (1 site per lane, 64-row windows), each with two,
+three and four steps per pass."""
 import numpy as np
 import pytest
 
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 # dtype, sites per lane (0: implied by the depth), steps per pass
-COMBOS = (("float32", 4, 2), ("float32", 2, 2), ("float32", 2, 3), ("float32", 2, 4), ("float64", 2, 2), ("float64", 0, 3), ("float64", 0, 4))
+COMBOS = (("float32", 2, 2), ("float32", 2, 3), ("float32", 2, 4), ("float64", 0, 2), ("float64", 1, 3), ("float64", 0, 4))
 
 
 def _run(pkg, mask, chunks, tau, u0, fuse, chunk=None, sites=0, dtype="float32", depth=2):
@@ -89,7 +89,7 @@ def test_fused_low_tau_clamp_and_mask_change(pkg, oracle_c):
     m1, m2 = _body(pkg, nx, ny, "naca4412", 20.0), _body(pkg, nx, ny, "naca4412", 5.0)
     fr, _ = oracle_c.run(m1, 300, 0.5004, 0.10, np.float32)
     fr, mr = oracle_c.run(m2, 100, 0.5004, 0.09, np.float32, f=fr)
-    for sites, depth in ((4, 2), (2, 2), (2, 3), (2, 4)):
+    for sites, depth in ((2, 2), (0, 3), (2, 4)):
         with pkg.Engine(nx, ny) as e:
             e.set_option("fuse_sites", sites)
             e.set_option("fuse_depth", depth)
@@ -141,7 +141,7 @@ def test_fused_toggle_midrun_and_4096(pkg):
 def test_fused_not_available(pkg):
     with pkg.Engine(256, 128, dtype="float64") as e:
         with pytest.raises(pkg.WTError):
-            e.set_option("fuse_sites", 4)           # fp64 vectors hold two sites
+            e.set_option("fuse_sites", 2)           # fp64: one site per lane
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_depth", 5)
         e.set_option("fuse_steps", 2)
@@ -149,7 +149,8 @@ def test_fused_not_available(pkg):
         assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 3 and e.get_option("fuse_sites") == 1    # fp64: one site per lane
         e.set_option("fuse_depth", 2)
         e.step(5, 0.58, 0.06)
-        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 2 and e.get_option("fuse_sites") == 2
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 2 and e.get_option("fuse_sites") == 1
+        assert e.get_option("single_steps") == 1.0      # 7 = 3 + 2 + 2, then 5 = 2 + 2 + 1
     with pkg.Engine(12, 64) as e:                   # fewer than 16 columns: two steps per pass at most
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_depth", 3)
@@ -161,9 +162,9 @@ def test_fused_not_available(pkg):
             e.set_option("fuse_steps", 2)
         with pytest.raises(pkg.WTError):
             e.set_option("no_such_option", 1)
-    with pkg.Engine(256, 130) as e:                 # NY % 4 != 0: two sites per lane only
+    with pkg.Engine(256, 130) as e:                 # fp32: two sites per lane, nothing else
         with pytest.raises(pkg.WTError):
-            e.set_option("fuse_sites", 4)
+            e.set_option("fuse_sites", 4)           # the 16-byte-vector kernels of round 2 are gone
         with pytest.raises(pkg.WTError):
             e.set_option("fuse_sites", 3)
         e.set_option("fuse_steps", 2)
@@ -202,13 +203,12 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
 
 
 @pytest.mark.parametrize("nranks,halo,nx,ny,chunks,dtype,sites,depth", [
-    (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 4, 2),
-    (3, 7, 768, 512, [40], "float32", 4, 2),
-    (4, 16, 2048, 512, [33, 18], "float32", 4, 2),
-    (2, 1, 512, 256, [9], "float32", 4, 2),              # halo 1: never two exact ghost columns -> single steps only
-    (8, 16, 4096, 256, [50], "float32", 4, 2),
+    (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 2, 2),
+    (3, 7, 768, 512, [40], "float32", 0, 2),
+    (2, 1, 512, 256, [9], "float32", 2, 2),              # halo 1: never two exact ghost columns -> single steps only
+    (8, 16, 4096, 256, [50], "float32", 2, 2),
     (4, 16, 2048, 512, [33, 18], "float32", 2, 2),
-    (3, 7, 768, 512, [40], "float64", 2, 2),
+    (3, 7, 768, 512, [40], "float64", 0, 2),
     (2, 4, 512, 256, [1, 2, 3, 8, 21], "float32", 2, 3),
     (3, 7, 768, 512, [40], "float32", 2, 3),
     (3, 7, 768, 512, [40], "float64", 0, 3),
@@ -256,7 +256,7 @@ def test_fuse_auto_only_where_it_pays(pkg):
             e.set_option("fuse_steps", 1)
             e.set_mask(np.zeros((e.ny, e.nx_global), np.uint8)); e.init_equilibrium(0.06)
         assert small.get_option("fuse_active") == 0.0 and big.get_option("fuse_active") == 1.0
-        assert big.get_option("fuse_sites") == 2          # 8 columns per 256-row unit: the 128-row windows are chosen
+        assert big.get_option("fuse_sites") == 2
         small.set_option("fuse_steps", 2)
         assert small.get_option("fuse_active") == 1.0
         small.step(6, 0.58, 0.06); big.step(6, 0.58, 0.06)
@@ -267,7 +267,7 @@ def test_fuse_auto_only_where_it_pays(pkg):
         assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(4, 2), (3, 2), (4, 1)]
         for e in (wide, slab, f64):
             e.set_option("fuse_depth", 2)
-        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(2, 4), (2, 2), (2, 2)]
+        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(2, 2), (2, 2), (2, 1)]
 
 
 def test_set_mask_stays_interactive(pkg):
@@ -285,3 +285,29 @@ def test_set_mask_stays_interactive(pkg):
             assert e.get_option("fuse_active") == 1.0
             assert sorted(ts)[len(ts) // 2] <= limit_ms, ts
             e.step(6, 0.58, 0.06)
+
+
+def test_remainder_of_one_never_falls_back_to_single_steps(pkg, oracle_c):
+    """fuse_stride: step(5), step(9), step(13) on a depth-4 plan split as 3 + 2, 4 + 3 + 2, 4 + 4 + 3 + 2 — never a pass plus a single
+    k_step, which would clear the seam buffer and send the next pass through the halo kernels' gather path.  Same for 4 = 2 + 2 and
+    7 = 3 + 2 + 2 on a depth-3 plan."""
+    nx, ny = 4096, 1024
+    mask = _body(pkg, nx, ny, "naca2412", 6.0)
+    fr, mr = oracle_c.run(mask, 27, 0.58, 0.06, np.float32)
+    with pkg.Engine(nx, ny) as e:
+        e.set_option("fuse_depth", 4)
+        e.set_mask(mask); e.init_equilibrium(0.06)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") == 4
+        for n, passes in ((5, 2), (9, 3), (13, 4)):
+            p0 = e.get_option("passes")
+            e.step(n, 0.58, 0.06)
+            assert e.get_option("passes") - p0 == passes
+        assert e.get_option("single_steps") == 0
+        assert bits_equal(e.read_f(), fr) and all(bits_equal(a, b) for a, b in zip(e.read_macro(), mr))
+    with pkg.Engine(nx, ny) as e:
+        e.set_option("fuse_depth", 3)
+        e.set_mask(mask); e.init_equilibrium(0.06)
+        for n in (4, 7, 4, 5, 7):
+            e.step(n, 0.58, 0.06)
+        assert e.get_option("single_steps") == 0 and e.info().steps_done == 27
+        assert bits_equal(e.read_f(), fr)

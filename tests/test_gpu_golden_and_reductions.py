@@ -15,13 +15,16 @@ RUNS_F32 = sorted(glob.glob(os.path.join(GOLDEN, "run_*_f32.npz")))
 RUNS_ALL = sorted(glob.glob(os.path.join(GOLDEN, "run_*.npz")))
 
 
-def _drive(pkg, g):
-    """Drives a WindTunnel through a golden run with the page's controls (AoA slider, U0 slider)."""
+def _drive(pkg, g, options=None):
+    """Drives a WindTunnel through a golden run with the page's controls (AoA slider, U0 slider).
+    `options`: engine options set before the first step (forces one kernel form onto the small golden lattices)."""
     nx, ny, steps = int(g["nx"]), int(g["ny"]), int(g["steps"])
     sched = json.loads(str(g["schedules"]))
     events = sorted({0, steps} | {e["step"] for e in sched["aoa_schedule"]} | {e["step"] for e in sched["u0_schedule"]})
     wt = pkg.WindTunnel(shape=str(g["shape"]), nx=nx, ny=ny, aoa_deg=float(g["aoa"]), u0=float(g["u0"]),
                         tau=float(g["tau"]), dtype="float32" if str(g["mode"]) == "f32" else "float64")
+    for name, value in (options or ()):
+        wt.engine.set_option(name, value)
     for a, b in zip(events[:-1], events[1:]):
         for e in sched["aoa_schedule"]:
             if e["step"] == a:
@@ -33,10 +36,25 @@ def _drive(pkg, g):
     return wt
 
 
+# every kernel form meets the fixtures generated from html:283-360 directly: the single-step kernel (depth 0) and the marching
+# kernels with 2 / 3 / 4 steps per pass forced onto these small lattices (fuse_steps = 2), each with the proved fast division by
+# tau and with the IEEE one
+FORMS = [(d, fd) for d in (0, 2, 3, 4) for fd in (1, 0)]
+
+
+@pytest.mark.parametrize("depth,fast_div", FORMS, ids=[f"depth{d}-fd{fd}" for d, fd in FORMS])
 @pytest.mark.parametrize("path", RUNS_ALL, ids=[os.path.basename(p)[:-4] for p in RUNS_ALL])
-def test_gpu_reproduces_reference_shader_goldens(pkg, path):
+def test_gpu_reproduces_reference_shader_goldens(pkg, path, depth, fast_div):
     g = np.load(path)
-    with _drive(pkg, g) as wt:
+    opts = [("fast_div", fast_div)]
+    if depth:
+        opts += [("fuse_depth", depth), ("fuse_steps", 2)]
+    else:
+        opts += [("fuse_steps", 0)]
+    with _drive(pkg, g, opts) as wt:
+        if depth:       # the forced plan must really be the one that ran (mask changes mid-run rebuild it in place)
+            assert wt.engine.get_option("fuse_active") == 1.0 and wt.engine.get_option("fuse_depth") == depth
+            assert wt.engine.get_option("single_steps") <= int(g["steps"]) // 2
         rho, ux, uy = wt.read_macro()
         f = wt.read_f()
     # stated fp tolerance ...

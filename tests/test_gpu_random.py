@@ -38,16 +38,14 @@ def test_random_case(pkg, oracle_c, seed):
     steps = [int(v) for v in rng.integers(1, 14, size=3)]
     mask = _random_mask(rng, nx, ny)
     ref_f, ref_m = oracle_c.run(mask, sum(steps), tau, u0, np.dtype(dtype))
-    for fuse, depth in ((0, 0), (4, 2), (2, 2), (2, 3), (2, 4)):     # single steps; marching kernel: sites per lane, steps per pass
+    for fuse, depth in ((0, 0), (2, 2), (2, 3), (2, 4)):     # single steps; marching kernels: steps per pass
         with pkg.Engine(nx, ny, dtype=dtype) as e:
             e.set_option("fuse_steps", 0)
             if fuse:
-                sites = fuse if not (dtype == "float64" and depth >= 3) else 0      # fp64, three steps: one site per lane, implied
-                if (sites and ny % sites) or nx < (16 if depth >= 3 else 8) or (dtype == "float64" and fuse == 4):
+                sites = 2 if dtype == "float32" else 1
+                if ny % sites or nx < (8 if depth == 2 and dtype == "float32" else 16):
                     continue
                 e.set_option("fuse_chunk", int(rng.integers(1, 40)))
-                if sites:
-                    e.set_option("fuse_sites", sites)
                 e.set_option("fuse_depth", depth)
                 e.set_option("fuse_steps", 2)
             e.set_mask(mask); e.init_equilibrium(u0)
