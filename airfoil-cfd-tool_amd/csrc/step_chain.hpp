@@ -1,0 +1,519 @@
+// step_chain.hpp — marching units that SHARE their edge columns instead of recomputing them.
+//
+// A solo unit of a T-step pass (step_march3.hpp) recomputes 2 (T-1) columns of its neighbours: level 1 of T-1 columns on either side,
+// level 2 of T-2, ...  On a column slab of an 8-way split a unit has 8-9 columns of its own and a third of its work is that overlap
+// (3 L + 8 stage executions for 3 L useful ones).  Here the four waves of a workgroup take four consecutive units of one window and
+// march them in ALTERNATING directions,
+//
+//        <---- A0 ----|---- B0 ---->   <---- A1 ----|---- B1 ---->
+//               start seam        end seam        start seam
+//
+// so that both units of a pair begin at their common seam, and the inner units B0 and A1 finish at theirs.  At a start seam each
+// unit publishes, level by level, the three populations of its first column that move across the seam (LDS, one workgroup barrier
+// per level) and takes its partner's in place of the "column behind" it would otherwise have recomputed; at an end seam the same
+// happens with the last column and the "column ahead".  No site is computed twice inside the block; only its two outer ends
+// (A0's left, B1's right) still overlap with the neighbouring blocks.  Stage executions per unit: 3 L + 1.5 on average instead of
+// 3 L + 8 (T = 3), 4 L + 3 instead of 4 L + 18 (T = 4).
+//
+// The fill and drain iterations are PEELED (an iteration template with a compile-time stage mask) rather than run on don't-care
+// values, and the barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier): the prefetched column and the stores of the
+// previous iteration stay in flight across them.
+//
+// Chain blocks are plain interior fluid throughout (the planner checks the window-tile classes of the block's whole footprint and
+// keeps it away from the inlet / outlet columns; every unit holds at least depth + 1 columns): no mask, no bounce codes, no class tests.  Everything else — body, inlet,
+// outlet, short units, two-step passes — stays with the solo units of step_march3.hpp, in the same launch.
+// Every site still goes through the arithmetic of k_step once per level: bit-identical results.
+#pragma once
+#include "step_march3.hpp"
+
+namespace wt {
+
+enum { MU_CHAIN = 2, MU_DIR_NEG = 4, MU_END_SHARED = 8 };      // MarchUnit::flags, beside MU_OUTLET_AFTER
+
+template <typename T, int S, int DEPTH>
+struct ChainLds {
+    // [phase: 0 start seam, 1 end seam][level - 1][position of the unit in its block][population of the triple][lane]
+    MV<T, S> x[2][DEPTH - 1][4][3][64];
+    int flag[2][DEPTH - 1][4];           // 1 once the triple above has been written (each slot is written once per launch)
+};
+
+// Hand-over of a triple between two waves of a workgroup WITHOUT a barrier: the producer writes the data, then the flag (LDS operations of one
+// wave complete in order; the wait in between makes that explicit); the consumer polls the flag just before the stage that needs the data —
+// one stage or more after its partner published, so the poll almost always succeeds at once.  (A workgroup barrier per level cost 8 % of a
+// three-step unit and 18 % of a four-step one on a 544-column slab: four waves on four SIMDs, each sharing its SIMD with another workgroup's
+// wave, are never in step.)  Both waves are resident (same workgroup), so the poll cannot dead-lock.
+template <typename V>
+__device__ __forceinline__ void chain_publish(V (&slot)[3][64], int &flag, int lane, const V &a0, const V &a1, const V &a2)
+{
+    slot[0][lane] = a0;
+    slot[1][lane] = a1;
+    slot[2][lane] = a2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *(volatile int *)&flag = 1;
+}
+template <typename V>
+__device__ __forceinline__ void chain_receive(const V (&slot)[3][64], const int &flag, int lane, V (&r)[3])
+{
+#ifndef WT_CHAIN_NOBARRIER   // (timing experiment: no synchronisation at all — wrong results)
+    while (__builtin_amdgcn_readfirstlane(*(const volatile int *)&flag) == 0) __builtin_amdgcn_s_sleep(1);
+#endif
+    asm volatile("" ::: "memory");
+    r[0] = slot[0][lane];
+    r[1] = slot[1][lane];
+    r[2] = slot[2][lane];
+}
+
+// populations that move in the marching direction (they come from the column BEHIND) and against it (from the column AHEAD),
+// in the order (straight, moving up, moving down)
+template <int DIR> struct ChainPops;
+template <> struct ChainPops<1> { static constexpr int B0 = 1, B1 = 5, B2 = 8, A0 = 3, A1 = 6, A2 = 7; };
+template <> struct ChainPops<-1> { static constexpr int B0 = 3, B1 = 6, B2 = 7, A0 = 1, A1 = 5, A2 = 8; };
+
+// one more application of STEP_FS in registers (plain interior fluid): level k+1 of column c from level k of the column behind
+// (`mb`: its three populations moving forward), of column c itself (`Gc`) and of the column ahead (`ma`: three populations moving
+// backward); `hv` = column c's halo-table word (lanes 0..5, as in march_stage)
+template <int DIR, bool WANT_MACRO, int FD, typename T, int S>
+__device__ __forceinline__ void chain_stage(const MarchParams<T> &p, int j0, int lane, bool far_win, const T (&feq0)[9], const MV<T, S> (&mb)[3],
+                                            const MV<T, S> (&Gc)[9], const MV<T, S> (&ma)[3], T hv, MV<T, S> (&out)[9], MV<T, S> (&mac)[3])
+{
+    typedef MV<T, S> V3;
+    typedef ChainPops<DIR> P;
+    const T hb2 = readlane_t(hv, 0), hb5 = readlane_t(hv, 1), hb6 = readlane_t(hv, 2), ha4 = readlane_t(hv, 3), ha7 = readlane_t(hv, 4),
+            ha8 = readlane_t(hv, 5);
+    // halo value of population k's row outside the window (5, 6 from below; 7, 8 from above)
+    auto edge = [&](int k) { return k == 5 ? hb5 : (k == 6 ? hb6 : (k == 7 ? ha7 : ha8)); };
+    V3 fin[9];
+    fin[0] = Gc[0];
+    fin[2] = m_below(Gc[2], lane, hb2);
+    fin[4] = m_above(Gc[4], lane, ha4);
+    fin[P::B0] = mb[0];
+    fin[P::B1] = m_below(mb[1], lane, edge(P::B1));
+    fin[P::B2] = m_above(mb[2], lane, edge(P::B2));
+    fin[P::A0] = ma[0];
+    fin[P::A1] = m_below(ma[1], lane, edge(P::A1));
+    fin[P::A2] = m_above(ma[2], lane, edge(P::A2));
+    march_collide<T, S, FD, WANT_MACRO>(fin, p.fdv, p.tau, out, mac);
+    if (far_win) march_far_rows<T, S, WANT_MACRO>(j0, p.g.ny, p.U0, feq0, out, mac);
+}
+
+template <int DIR, int DEPTH, bool EMIT, int FD, typename T, int S>
+struct ChainUnit {
+    typedef MV<T, S> V3;
+    typedef ChainPops<DIR> P;
+    static constexpr unsigned HREC = 8 * sizeof(T);
+    static constexpr int FULL = (1 << DEPTH) - 1;
+
+    const MarchParams<T> &p;
+    March3Addr<T, S> &m;
+    const __amdgpu_buffer_rsrc_t (&rh)[3];
+    const T (&feq0)[9];
+    ChainLds<T, S, DEPTH> &lds;
+    unsigned hoff;
+    int j0, lane, pos;
+    bool far_win;
+    int x_lo, x_hi;              // columns whose streamed inputs may be requested (prefetches beyond the unit's last column re-load it)
+    int seam_col;
+
+    V3 in[9];                    // streamed inputs of the next level-1 column
+    V3 sm[DEPTH - 1][3];         // level k (index k-1): forward-moving populations of the column two behind the front of that level
+    V3 sc[DEPTH - 1][9];         //                      all nine of the column one behind it
+    T hv[DEPTH - 1];             // halo-table words of the columns the NEXT iteration's stages 2 .. DEPTH produce
+
+    __device__ __forceinline__ ChainUnit(const MarchParams<T> &p_, March3Addr<T, S> &m_, const __amdgpu_buffer_rsrc_t (&rh_)[3], const T (&feq0_)[9],
+                                         ChainLds<T, S, DEPTH> &lds_)
+        : p(p_), m(m_), rh(rh_), feq0(feq0_), lds(lds_) {}
+
+    __device__ __forceinline__ unsigned hcol(int c) const { return (unsigned)(c > 0 ? c : 0) * HREC; }
+    __device__ __forceinline__ int clampx(int x) const { return x < x_lo ? x_lo : (x > x_hi ? x_hi : x); }
+
+    // One iteration with the level-1 front at column x: stage 1 (bit 0 of MASK) = STEP_FS on the streamed inputs of column x; stage k
+    // (bit k-1) = level k of column x - (k-1) DIR; the last stage stores.  Hand-over hooks (0 = none):
+    //   RS: take the start-seam partner's level-RS triple as the column behind, just before stage RS + 1;
+    //   PS: publish this unit's level-PS triple for the start-seam partner, right after stage PS;
+    //   RE: take the end-seam partner's level-RE triple as the column ahead of stage RE + 1, the first stage of this (drain) iteration;
+    //   PE: publish this unit's level-PE triple for the end-seam partner, right after stage PE.
+    template <int MASK, int RS, int PS, int RE, int PE>
+    __device__ __forceinline__ void iter(int x)
+    {
+        const MarchAddr<T, S> &a = m.a;
+        constexpr bool S1 = (MASK & 1) != 0, LAST = (MASK >> (DEPTH - 1)) != 0;
+        V3 nxt[9];
+        if (S1) march_load_stream(a, clampx(x + DIR), nxt);
+        T hvn[DEPTH - 1];
+#pragma unroll
+        for (int k = 1; k < DEPTH; k++) hvn[k - 1] = halo_load<T>(rh[k - 1], hoff, hcol(x + DIR - k * DIR));
+        Seam3 sp;
+        if (LAST) sp = seam3_fetch(m);
+        V3 G[DEPTH + 1][9], mac[3];          // G[k] = level k computed in this iteration (G[DEPTH] = what is stored)
+        if (S1) {
+            march_step1<false, FD, T, S>(p, a, x, j0, far_win, false, false, feq0, in, G[1]);
+            if (PS == 1) chain_publish(lds.x[0][0][pos], lds.flag[0][0][pos], lane, G[1][P::A0], G[1][P::A1], G[1][P::A2]);
+            if (PE == 1) chain_publish(lds.x[1][0][pos], lds.flag[1][0][pos], lane, G[1][P::B0], G[1][P::B1], G[1][P::B2]);
+        }
+#pragma unroll
+        for (int k = 2; k <= DEPTH; k++) {
+            if (!((MASK >> (k - 1)) & 1)) continue;
+            V3 ma[3];
+            if ((MASK >> (k - 2)) & 1) { ma[0] = G[k - 1][P::A0]; ma[1] = G[k - 1][P::A1]; ma[2] = G[k - 1][P::A2]; }
+            else chain_receive(lds.x[1][k - 2][pos ^ 3], lds.flag[1][k - 2][pos ^ 3], lane, ma);           // RE == k - 1 (positions 1 <-> 2)
+            if (RS == k - 1) chain_receive(lds.x[0][k - 2][pos ^ 1], lds.flag[0][k - 2][pos ^ 1], lane, sm[k - 2]);
+            if (k == DEPTH) chain_stage<DIR, EMIT, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 2], G[k], mac);
+            else chain_stage<DIR, false, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 2], G[k], mac);
+            if (k < DEPTH && PS == k) chain_publish(lds.x[0][k - 1][pos], lds.flag[0][k - 1][pos], lane, G[k][P::A0], G[k][P::A1], G[k][P::A2]);
+            if (k < DEPTH && PE == k) chain_publish(lds.x[1][k - 1][pos], lds.flag[1][k - 1][pos], lane, G[k][P::B0], G[k][P::B1], G[k][P::B2]);
+        }
+        static_assert(RE == 0 || (((MASK >> RE) & 1) && !((MASK >> (RE - 1)) & 1)), "RE names the level below the first stage of a drain iteration");
+        if (LAST) {
+            pin_after(G[DEPTH]);
+            if (S1) wait_for_column(nxt, hvn[0], hvn[1], DEPTH == 4 ? hvn[DEPTH - 2] : T(0));
+            const int c = x - (DEPTH - 1) * DIR;
+            march3_store<EMIT>(m, a.voff_st, c, G[DEPTH], mac);
+            seam3_flush(m, seam_col, sp);
+            seam_col = c;
+        }
+#pragma unroll
+        for (int k = 1; k < DEPTH; k++) {
+            hv[k - 1] = hvn[k - 1];
+            if (!((MASK >> (k - 1)) & 1)) continue;      // level k was not advanced: its carried columns stay
+            sm[k - 1][0] = sc[k - 1][P::B0]; sm[k - 1][1] = sc[k - 1][P::B1]; sm[k - 1][2] = sc[k - 1][P::B2];
+#pragma unroll
+            for (int q = 0; q < 9; q++) sc[k - 1][q] = G[k][q];
+        }
+        if (S1) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) in[q] = nxt[q];
+        }
+    }
+
+    // marched columns [ia, ib), at least DEPTH + 1 of them; the unit starts at its seam with unit pos ^ 1 and ends, when end_shared, at its
+    // seam with the other inner unit (positions 1 and 2), else on its own (DEPTH - 1 recomputed columns of the neighbouring block)
+    __device__ __forceinline__ void run(int ia, int ib, bool end_shared)
+    {
+        const MarchAddr<T, S> &a = m.a;
+        const int L = ib - ia;
+        const int xf = DIR > 0 ? ia : ib - 1;                                 // first column
+        const int p_end = end_shared ? L - 1 : L - 1 + (DEPTH - 1);           // last position whose level 1 is computed here
+        x_lo = DIR > 0 ? ia : ib - 1 - p_end;
+        x_hi = DIR > 0 ? ia + p_end : ib - 1;
+        seam_col = -1;
+#pragma unroll
+        for (int k = 0; k < DEPTH - 1; k++) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) sc[k][q] = mv_splat<T, S>(feq0[q]);
+            sm[k][0] = sc[k][1]; sm[k][1] = sc[k][5]; sm[k][2] = sc[k][8];
+        }
+        march_load_stream(a, xf, in);
+#pragma unroll
+        for (int k = 1; k < DEPTH; k++) hv[k - 1] = halo_load<T>(rh[k - 1], hoff, hcol(xf - k * DIR));
+        // ---- start seam: iteration q brings level q + 1 of the first column into being and publishes its backward-moving populations; the
+        //      partner's forward-moving ones are taken one iteration later, just before the stage that needs them
+        iter<1, 0, 1, 0, 0>(xf);
+        iter<3, 1, 2, 0, 0>(xf + DIR);
+        if constexpr (DEPTH == 3) {
+            iter<7, 2, 0, 0, 0>(xf + 2 * DIR);
+        } else {
+            iter<7, 2, 3, 0, 0>(xf + 2 * DIR);
+            iter<15, 3, 0, 0, 0>(xf + 3 * DIR);
+        }
+        // ---- the body of the unit
+        const int q_last = end_shared ? L - 2 : p_end;
+#pragma unroll 1
+        for (int q = DEPTH; q <= q_last; q++) iter<FULL, 0, 0, 0, 0>(xf + q * DIR);
+        // ---- end seam: the last column's forward-moving populations go out as soon as each level exists; the partner's backward-moving
+        //      ones are taken at the head of the next (drain) iteration
+        if (end_shared) {
+            const int xl = xf + (L - 1) * DIR;
+            iter<FULL, 0, 0, 0, 1>(xl);
+            iter<(FULL & ~1), 0, 0, 1, 2>(xl + DIR);
+            if constexpr (DEPTH == 3) {
+                iter<(FULL & ~3), 0, 0, 2, 0>(xl + 2 * DIR);
+            } else {
+                iter<(FULL & ~3), 0, 0, 2, 3>(xl + 2 * DIR);
+                iter<(FULL & ~7), 0, 0, 3, 0>(xl + 3 * DIR);
+            }
+        }
+        seam3_flush(m, seam_col, seam3_fetch(m));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the marching kernel: solo units (step_march3.hpp) and chain blocks in one launch
+// ------------------------------------------------------------------------------------------------
+#ifdef WT_UNIT_CLOCKS         // diagnostic build (tools/unit_clocks.py): how long does every unit of a pass take?  [unit] = {start, end} (s_memtime)
+__device__ unsigned long long g_unit_clk[2 * 16384];
+struct UnitClock {
+    int u, lane;
+    unsigned long long t0;
+    __device__ UnitClock(int u_, int lane_) : u(u_), lane(lane_), t0(__builtin_amdgcn_s_memtime()) {}
+    __device__ ~UnitClock()
+    {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && u < 16384) { g_unit_clk[2 * u] = t0; g_unit_clk[2 * u + 1] = t1; }
+    }
+};
+#endif
+
+template <typename T, int S, int DEPTH, bool EMIT, int FD>
+__global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
+{
+    constexpr int M3_WIN = 64 * S;
+    constexpr unsigned EB = sizeof(T);
+    const Geom &g = p.g;
+    const int lane = threadIdx.x & 63;
+    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= p.nunits) return;
+    if (p.rev & 1) u = p.nunits - 1 - u;
+    const MarchUnit un = p.units[u];
+    const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
+    const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
+    if (ib <= ia) return;
+#ifdef WT_UNIT_CLOCKS
+    UnitClock unit_clock(u, lane);
+#endif
+    const int row0 = w * M3_WIN;
+    const int j0 = row0 + lane * S;
+    const bool far_win = (w == 0) || (row0 + M3_WIN >= g.ny);
+    March3Addr<T, S> m;
+    MarchAddr<T, S> &a = m.a;
+    m.young = (blockIdx.x * 2 >= gridDim.x) ? 1 : 0;
+    if (p.prio == 2) march_prio(m.young);
+    a.rs = march_rsrc(p.fs, p.lat_bytes);
+    a.rd = march_rsrc(p.fd, p.lat_bytes);
+    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * EB));
+    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * EB;
+    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * EB : p.lat_bytes;
+    a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
+    a.lane = lane;
+    const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 8u * EB;
+    const __amdgpu_buffer_rsrc_t rh1 = march_rsrc(p.halo, hbytes), rh2 = march_rsrc(p.halo2, hbytes), rh3 = march_rsrc(p.halo3, hbytes);
+    unsigned hoff;
+    {
+        const int hl = lane < 6 ? lane : 0;
+        const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
+        const int slot = hl < 3 ? hl : hl + 1;
+        const int seam = hl < 3 ? w : w + 1;
+        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 8 + slot) * EB;
+    }
+    {
+        // per wave, in elements: below[40] (slot k = the window's last four rows of direction k, staged by the last 4/S lanes; slot
+        // 9 stays zero), above[40] (rows 0..3, the first 4/S lanes), then a scratch area for the other lanes' writes
+        constexpr int EDGE = 4 / S;                       // lanes that hold four rows
+        constexpr int NCH = 10 * (int)sizeof(T) / 4;      // 16-byte chunks of one half
+        __shared__ __attribute__((aligned(16))) T seam_lds[4][2 * M3_SHALF + 176];
+        T *wl = &seam_lds[threadIdx.x >> 6][0];
+        m.lds_w = lane >= 64 - EDGE ? wl + (lane - (64 - EDGE)) * S : (lane < EDGE ? wl + M3_SHALF + lane * S : wl + 2 * M3_SHALF + S * lane);
+        m.lds_r = reinterpret_cast<const char *>(wl) + 16 * (lane < NCH ? lane : 0);
+        if (lane < M3_SHALF) { wl[lane] = T(0); wl[lane + M3_SHALF] = T(0); }
+        const unsigned sbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * EB);
+        m.rs3 = march_rsrc(p.seams, sbytes);
+        const unsigned rec = (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * EB);
+        m.voff_lo = lane < NCH ? (unsigned)w * rec + (unsigned)(M3_SHALF * EB) + (unsigned)lane * 16u : sbytes;
+        m.voff_hi = lane < NCH ? (unsigned)(w + 1) * rec + (unsigned)lane * 16u : sbytes;
+    }
+    T feq0[9];
+    feq_all<T>(T(1), p.U0, T(0), feq0);
+
+    // classes of columns ia-PAD .. ib+PAD-1 (lane l <-> column ia-PAD+l): two 64-bit scalars
+    constexpr int PAD = DEPTH == 4 ? 3 : 2;
+    unsigned long long nonfast_m, solid_m;
+    {
+        const int n = ib - ia + 2 * PAD;
+        const int col = ia - PAD + lane;
+        uint8_t cls = WC_FAST;
+        if (lane < n && col >= -1 && col <= g.nxl) cls = p.wcls[(long)w * (g.nxl + 2) + col + 1];
+        nonfast_m = __ballot(cls != WC_FAST);
+        solid_m = __ballot(cls == WC_SOLID);
+    }
+    const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= PAD + 1 && ib + g.gi0 <= g.nx_g - PAD - 1 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
+    if constexpr (DEPTH >= 3) {
+        // chain blocks (step_chain.hpp): the four waves of this workgroup share the edge columns of their units through LDS.  The flag is
+        // per block (set by chain_blocks on the host for all four units or none), so the barriers inside are workgroup-uniform.
+        if (uflags & MU_CHAIN) {
+            constexpr int FDP = (DEPTH == 4 && sizeof(T) == 4) ? (FD | MARCH_FD_PACKED) : FD;
+            __shared__ ChainLds<T, S, DEPTH> chain_lds;
+            const __amdgpu_buffer_rsrc_t rhs[3] = {rh1, rh2, rh3};
+            const bool end_shared = (uflags & MU_END_SHARED) != 0;
+            if (lane < 2 * (DEPTH - 1)) chain_lds.flag[lane / (DEPTH - 1)][lane % (DEPTH - 1)][u & 3] = 0;     // my own hand-over flags ...
+            __syncthreads();                                                                              // ... before anybody polls them
+            if (uflags & MU_DIR_NEG) {
+                ChainUnit<-1, DEPTH, EMIT, FDP, T, S> cu(p, m, rhs, feq0, chain_lds);
+                cu.hoff = hoff; cu.j0 = j0; cu.lane = lane; cu.pos = u & 3; cu.far_win = far_win;
+                cu.run(ia, ib, end_shared);
+            } else {
+                ChainUnit<1, DEPTH, EMIT, FDP, T, S> cu(p, m, rhs, feq0, chain_lds);
+                cu.hoff = hoff; cu.j0 = j0; cu.lane = lane; cu.pos = u & 3; cu.far_win = far_win;
+                cu.run(ia, ib, end_shared);
+            }
+            return;
+        }
+    }
+    if (DEPTH == 4) {
+        constexpr int FDP = sizeof(T) == 4 ? (FD | MARCH_FD_PACKED) : FD;     // fp32: the packed two-site collision (step_march.hpp)
+        if (lean) march_unit4<false, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit4<true, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+    } else if (DEPTH == 3) {
+        if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit3<true, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+    } else {
+        if (lean) march_unit3_d2<false, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        else march_unit3_d2<true, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: blocks of four units
+// ------------------------------------------------------------------------------------------------
+// Re-orders a plan into blocks of four consecutive units of one window (one workgroup each), pads every window to whole blocks with
+// empty units, and marks the blocks that can run as a chain: four units of at least `depth` columns each whose whole footprint
+// (`pad` columns beyond either end included) is FAST and clear of the inlet / outlet columns.  Blocks are listed chunk-major (the
+// windows of one column range are neighbours), like the units of the solo plan.
+static inline void chain_blocks(MarchPlan &pl, const uint8_t *wcls, const Geom &g, int depth, bool enable)
+{
+    const int ld = g.nxl + 2, pad = depth == 4 ? 3 : 2;
+    std::vector<std::vector<MarchUnit>> per((size_t)pl.nwin);
+    for (const MarchUnit &u : pl.units) per[(size_t)u.w].push_back(u);
+    struct Block { MarchUnit u[4]; };
+    std::vector<Block> blocks;
+    for (int w = 0; w < pl.nwin; w++) {
+        std::vector<MarchUnit> &v = per[(size_t)w];
+        std::sort(v.begin(), v.end(), [](const MarchUnit &a, const MarchUnit &b) { return a.ia < b.ia; });
+        for (size_t i = 0; i < v.size(); i += 4) {
+            Block b;
+            const size_t n = std::min<size_t>(4, v.size() - i);
+            for (size_t k = 0; k < 4; k++) b.u[k] = k < n ? v[i + k] : MarchUnit{0, 0, w, 0};
+            bool chain = enable && n == 4;
+            if (chain) {
+                const int lo = b.u[0].ia - pad, hi = b.u[3].ib + pad;            // footprint [lo, hi)
+                chain = lo + g.gi0 >= 1 && hi + g.gi0 <= g.nx_g - 1 && lo >= 0 && hi <= g.nxl;
+                for (int k = 0; k < 4 && chain; k++)
+                    chain = b.u[k].ib - b.u[k].ia >= depth + 1 && !(b.u[k].flags & MU_OUTLET_AFTER) && (k == 0 || b.u[k].ia == b.u[k - 1].ib);
+                const uint8_t *c = wcls + (size_t)w * ld + 1;
+                for (int x = lo; x < hi && chain; x++) chain = c[x] == WC_FAST;
+            }
+            if (chain) {
+                b.u[0].flags |= MU_CHAIN | MU_DIR_NEG;
+                b.u[1].flags |= MU_CHAIN | MU_END_SHARED;
+                b.u[2].flags |= MU_CHAIN | MU_DIR_NEG | MU_END_SHARED;
+                b.u[3].flags |= MU_CHAIN;
+            }
+            blocks.push_back(b);
+        }
+    }
+    std::stable_sort(blocks.begin(), blocks.end(), [](const Block &x, const Block &y) { return x.u[0].ia != y.u[0].ia ? x.u[0].ia < y.u[0].ia : x.u[0].w < y.u[0].w; });
+    pl.units.clear();
+    for (const Block &b : blocks)
+        for (int k = 0; k < 4; k++) pl.units.push_back(b.u[k]);
+}
+
+// The cut by time (build_march_plan_timed) with chain blocks: sweeping a window from the inlet side, a chain block of four units — outer,
+// inner, inner, outer, with as many columns as the time limit t leaves after the chain overheads — is placed wherever its whole footprint is
+// plain fluid and clear of the tunnel's ends; elsewhere solo units are cut by time as before.  A chain block counts four units, and the
+// smallest t whose plan has at most target_units units is found by bisection.  Units come out in chunk-major order with every aligned group
+// of four either one chain block or four solo units (the last solo group of the list is padded with empty units).
+struct ChainCost { double over, tail, ov_inner, ov_outer; };     // solo: columns iterated beyond the unit's own, outlet extra; chain: per-unit overheads in columns
+static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &g, int win, long target_units, double alpha, const MarchRange &r, int min_last,
+                                               int max_len, int depth, const ChainCost &cc)
+{
+    MarchPlan pl;
+    const int nwin = march_nwin(g.ny, win), ld = g.nxl + 2, pad = depth == 4 ? 3 : 2;
+    pl.nwin = nwin;
+    const int ncol = r.i_end - r.i_begin;
+    if (ncol <= 0) return pl;
+    if (target_units < nwin) target_units = nwin;
+    const int E = (int)(cc.over / 2) + 2;
+    const int n = ncol + 2 * E;
+    std::vector<double> C((size_t)nwin * (n + 1), 0.0);        // running cost, as in build_march_plan_timed
+    std::vector<int> NF((size_t)nwin * (g.nxl + 3), 0);        // NF[w][x + 2] = non-FAST columns among -1 .. x
+    for (int w = 0; w < nwin; w++) {
+        const uint8_t *c = wcls + (size_t)w * ld + 1;
+        double *Cw = &C[(size_t)w * (n + 1)];
+        for (int k = 0; k < n; k++) {
+            const int x = r.i_begin - E + k, gi = x + g.gi0;
+            double cost = 0.0;
+            if (gi >= 0 && gi < g.nx_g) cost = (x >= -1 && x <= g.nxl && c[x] != WC_FAST) ? 1.0 + alpha : 1.0;
+            Cw[k + 1] = Cw[k] + cost;
+        }
+        int *Nw = &NF[(size_t)w * (g.nxl + 3)];
+        for (int x = -1; x <= g.nxl; x++) Nw[x + 2] = Nw[x + 1] + (c[x] != WC_FAST);
+    }
+    auto Cf = [&](const double *Cw, double x) {
+        double k = x - (r.i_begin - E);
+        if (k < 0) k = 0;
+        if (k > n) k = n;
+        const int k0 = (int)k;
+        return k0 >= n ? Cw[n] : Cw[k0] + (k - k0) * (Cw[k0 + 1] - Cw[k0]);
+    };
+    auto unit_time = [&](const double *Cw, int ia, int ib) {
+        return Cf(Cw, ib + cc.over / 2) - Cf(Cw, ia - cc.over / 2) + ((r.outlet_after && ib == r.i_end) ? cc.tail : 0.0);
+    };
+    auto plain = [&](int w, int lo, int hi) {                  // columns [lo, hi) all FAST, inside the lattice and clear of the tunnel's ends
+        if (lo < 0 || hi > g.nxl || lo + g.gi0 < 1 || hi + g.gi0 > g.nx_g - 1) return false;
+        const int *Nw = &NF[(size_t)w * (g.nxl + 3)];
+        return Nw[hi + 1] - Nw[lo + 1] == 0;
+    };
+    struct Item { MarchUnit u[4]; int n; };                    // a chain block (n = 4) or one solo unit (n = 1)
+    auto cut = [&](int w, double t, std::vector<Item> *out) {
+        const double *Cw = &C[(size_t)w * (n + 1)];
+        const int Li = std::min((int)(t - cc.ov_inner), max_len), Lo = std::min((int)(t - cc.ov_outer), max_len);
+        const int B = 2 * Li + 2 * Lo;
+        int ia = r.i_begin;
+        long count = 0;
+        while (ia < r.i_end) {
+            const int rest = r.i_end - (ia + B);
+            if (Li >= depth + 1 && Lo >= depth + 1 && rest >= 0 && (rest == 0 ? !r.outlet_after : rest >= min_last) && plain(w, ia - pad, ia + B + pad)) {
+                if (out) {
+                    Item it; it.n = 4;
+                    const int len[4] = {Lo, Li, Li, Lo};
+                    const int fl[4] = {MU_CHAIN | MU_DIR_NEG, MU_CHAIN | MU_END_SHARED, MU_CHAIN | MU_DIR_NEG | MU_END_SHARED, MU_CHAIN};
+                    int x = ia;
+                    for (int k = 0; k < 4; k++) { it.u[k] = MarchUnit{x, x + len[k], w, fl[k]}; x += len[k]; }
+                    out->push_back(it);
+                }
+                ia += B;
+                count += 4;
+                continue;
+            }
+            int ib = ia + 1;
+            const int cap = std::min(r.i_end, ia + max_len);
+            while (ib < cap && unit_time(Cw, ia, ib + 1) <= t) ib++;
+            if (r.i_end - ib > 0 && r.i_end - ib < min_last) {
+                if (r.i_end - min_last <= ia || (r.i_end - ia <= max_len + min_last - 1 && unit_time(Cw, ia, r.i_end) <= t)) ib = r.i_end;
+                else ib = r.i_end - min_last;
+            }
+            if (out) { Item it; it.n = 1; it.u[0] = MarchUnit{ia, ib, w, (r.outlet_after && ib == r.i_end) ? MU_OUTLET_AFTER : 0}; out->push_back(it); }
+            ia = ib;
+            count++;
+        }
+        return count;
+    };
+    auto total = [&](double t) { long s = 0; for (int w = 0; w < nwin; w++) s += cut(w, t, nullptr); return s; };
+    double lo = 0.0, hi = (double)max_len * (1.0 + alpha) + cc.over * (1.0 + alpha) + cc.tail + cc.ov_inner + 1.0;
+    if (total(hi) > target_units) lo = hi;
+    else {
+        // the count is not monotonic in t where a block starts or stops fitting, so scan downwards from a bisection estimate
+        for (int it = 0; it < 40; it++) {
+            const double mid = 0.5 * (lo + hi);
+            if (total(mid) <= target_units) hi = mid; else lo = mid;
+        }
+    }
+    std::vector<Item> items;
+    for (int w = 0; w < nwin; w++) cut(w, hi, &items);
+    std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.u[0].ia != y.u[0].ia ? x.u[0].ia < y.u[0].ia : x.u[0].w < y.u[0].w; });
+    std::vector<MarchUnit> solo;
+    long cols = 0, live = 0;
+    for (const Item &it : items) {
+        for (int k = 0; k < it.n; k++) { cols += it.u[k].ib - it.u[k].ia; live++; }
+        if (it.n == 4) { for (int k = 0; k < 4; k++) pl.units.push_back(it.u[k]); continue; }
+        solo.push_back(it.u[0]);
+        if (solo.size() == 4) { for (const MarchUnit &u : solo) pl.units.push_back(u); solo.clear(); }
+    }
+    if (!solo.empty()) {
+        while (solo.size() < 4) solo.push_back(MarchUnit{0, 0, solo[0].w, 0});
+        for (const MarchUnit &u : solo) pl.units.push_back(u);
+    }
+    pl.chunk = live ? (int)((double)cols / (double)live + 0.5) : 0;
+    return pl;
+}
+
+}  // namespace wt

@@ -285,6 +285,7 @@ struct MarchParams {
     T tau;
     T U0;
     int rev;
+    int prio;                  // experiment (WT_PRIO): 1 = the two waves of a SIMD take turns at issue priority, iteration by iteration; 2 = the later-dispatched half of the grid has priority
 };
 
 // S consecutive rows of one column and direction, held by one lane
@@ -958,9 +959,10 @@ struct MarchPlan {
 // the total is at most `target_units` (a multiple of `slots` chosen by the caller), or, when max_cost > 0, into
 // units of at most max_cost (tests, experiments).
 // min_last: least number of marched columns of a window's LAST unit (a four-step pass needs 2: the unit before the outlet unit
-// must end two columns short of the outlet column); max_len: most columns of a unit.
+// must end two columns short of the outlet column); max_len: most columns of a unit; parts_multiple: the units of a window come in
+// whole groups of that many where the window has at least one group (step_chain.hpp: blocks of four).
 static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int win, long target_units, int max_cost = 0, double alpha = 1.0,
-                                         const MarchRange *range = nullptr, int min_last = 1, int max_len = MARCH_MAX_CHUNK)
+                                         const MarchRange *range = nullptr, int min_last = 1, int max_len = MARCH_MAX_CHUNK, int parts_multiple = 1)
 {
     MarchPlan pl;
     const int nwin = march_nwin(g.ny, win), ld = g.nxl + 2;
@@ -990,6 +992,7 @@ static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int
         int parts = (int)(wcost[w] / target);
         if (max_cost > 0) parts = (int)((wcost[w] + target - 1e-9) / target);
         if (parts < 1) parts = 1;
+        if (max_cost <= 0 && parts_multiple > 1 && parts >= parts_multiple && (ncol + parts - 1) / parts < max_len) parts -= parts % parts_multiple;
         const double per = wcost[w] / parts;
         int ia = r.i_begin, done = 0;
         double acc = 0.0;
@@ -1004,6 +1007,84 @@ static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int
             }
         }
     }
+    // chunk-major order: the windows of one chunk are neighbours in the list (adjacent waves read adjacent kilobytes)
+    std::stable_sort(pl.units.begin(), pl.units.end(), [](const MarchUnit &x, const MarchUnit &y) { return x.ia != y.ia ? x.ia < y.ia : x.w < y.w; });
+    return pl;
+}
+
+// The same cut by TIME instead of by owned columns.  All units of a launch are resident together (whole rounds), so the launch takes as
+// long as its slowest unit, and a unit's time is the cost of every column it ITERATES over — its own and the `over` columns it recomputes
+// for its neighbours' sake (pipeline fill and drain: 2.7 iterations of a three-step pass, 4.5 of a four-step one), which in the body zone
+// are body columns too (per-unit clocks, tools/unit_clocks.py: with the cut by owned columns a two-column body unit of the bench mask took
+// 1.55 x as long as a ten-column plain one and set the pace of the whole launch).  time(ia, ib) = C(ib + over / 2) - C(ia - over / 2) with
+// C the running cost of the window's columns (a FAST column 1, any other 1 + alpha, nothing beyond the tunnel's ends) and `tail` more
+// for the unit that also emits the outlet column; the smallest t for which every window cut greedily into units of time <= t gives at
+// most target_units in total is found by bisection.
+static inline MarchPlan build_march_plan_timed(const uint8_t *wcls, const Geom &g, int win, long target_units, double alpha, const MarchRange &r, int min_last,
+                                               int max_len, double over, double tail)
+{
+    MarchPlan pl;
+    const int nwin = march_nwin(g.ny, win), ld = g.nxl + 2;
+    pl.nwin = nwin;
+    const int ncol = r.i_end - r.i_begin;
+    if (ncol <= 0) return pl;
+    if (target_units < nwin) target_units = nwin;
+    const int E = (int)(over / 2) + 2;                         // columns beyond the marched range that enter a unit's time
+    const int n = ncol + 2 * E;
+    std::vector<double> C((size_t)nwin * (n + 1), 0.0);        // C[w][k] = cost of columns i_begin - E .. i_begin - E + k - 1
+    for (int w = 0; w < nwin; w++) {
+        const uint8_t *c = wcls + (size_t)w * ld + 1;
+        double *Cw = &C[(size_t)w * (n + 1)];
+        for (int k = 0; k < n; k++) {
+            const int x = r.i_begin - E + k, gi = x + g.gi0;
+            double cost = 0.0;
+            if (gi >= 0 && gi < g.nx_g) cost = (x >= -1 && x <= g.nxl && c[x] != WC_FAST) ? 1.0 + alpha : 1.0;
+            Cw[k + 1] = Cw[k] + cost;
+        }
+    }
+    auto Cf = [&](const double *Cw, double x) {                // running cost up to (fractional) column x
+        double k = x - (r.i_begin - E);
+        if (k < 0) k = 0;
+        if (k > n) k = n;
+        const int k0 = (int)k;
+        return k0 >= n ? Cw[n] : Cw[k0] + (k - k0) * (Cw[k0 + 1] - Cw[k0]);
+    };
+    auto unit_time = [&](const double *Cw, int ia, int ib) {
+        return Cf(Cw, ib + over / 2) - Cf(Cw, ia - over / 2) + ((r.outlet_after && ib == r.i_end) ? tail : 0.0);
+    };
+    // cut one window for a time limit t; returns the number of units (and the cuts when `out` is given)
+    auto cut = [&](int w, double t, std::vector<MarchUnit> *out) {
+        const double *Cw = &C[(size_t)w * (n + 1)];
+        int ia = r.i_begin, count = 0;
+        while (ia < r.i_end) {
+            int ib = ia + 1;
+            const int cap = std::min(r.i_end, ia + max_len);
+            while (ib < cap && unit_time(Cw, ia, ib + 1) <= t) ib++;
+            if (r.i_end - ib > 0 && r.i_end - ib < min_last) {     // too short a last unit: take it in, or leave it min_last columns
+                if (r.i_end - min_last <= ia || (r.i_end - ia <= max_len + min_last - 1 && unit_time(Cw, ia, r.i_end) <= t)) ib = r.i_end;
+                else ib = r.i_end - min_last;
+            }
+            if (out) out->push_back(MarchUnit{ia, ib, w, (r.outlet_after && ib == r.i_end) ? MU_OUTLET_AFTER : 0});
+            ia = ib;
+            count++;
+        }
+        return count;
+    };
+    auto total = [&](double t) { long s = 0; for (int w = 0; w < nwin; w++) s += cut(w, t, nullptr); return s; };
+    double lo = 0.0, hi = (double)max_len * (1.0 + alpha) + over * (1.0 + alpha) + tail + 1.0;
+    if (total(hi) > target_units) lo = hi;                     // the length cap forces more units than asked for: longest units
+    else {
+        for (int it = 0; it < 40; it++) {
+            const double mid = 0.5 * (lo + hi);
+            if (total(mid) <= target_units) hi = mid; else lo = mid;
+        }
+    }
+    const double t = hi;
+    pl.chunk = 0;
+    for (int w = 0; w < nwin; w++) cut(w, t, &pl.units);
+    long cols = 0;
+    for (const MarchUnit &u : pl.units) cols += u.ib - u.ia;
+    pl.chunk = pl.units.empty() ? 0 : (int)((double)cols / (double)pl.units.size() + 0.5);
     // chunk-major order: the windows of one chunk are neighbours in the list (adjacent waves read adjacent kilobytes)
     std::stable_sort(pl.units.begin(), pl.units.end(), [](const MarchUnit &x, const MarchUnit &y) { return x.ia != y.ia ? x.ia < y.ia : x.w < y.w; });
     return pl;

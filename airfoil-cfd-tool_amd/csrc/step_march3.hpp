@@ -298,8 +298,16 @@ __device__ unsigned long long g_m3_stamps[8];
 #define M3_STAMP(i) do { } while (0)
 #endif
 
+// issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate)
+__device__ __forceinline__ void march_prio(int hi)
+{
+    if (hi) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
+}
+
 template <typename T, int S>
 struct March3Addr {
+    int young;                           // this workgroup belongs to the later-dispatched half of the grid (the second wave of its SIMD)
     MarchAddr<T, S> a;                   // lattice / macro descriptors and offsets (its seam fields are unused here)
     __amdgpu_buffer_rsrc_t rs3;          // seam buffer S3
     unsigned voff_lo, voff_hi;           // lanes 0 .. 10 sizeof(T)/4 - 1: byte offsets of their 16-byte chunk in the two half records this window writes
@@ -463,6 +471,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     // stores makes hipcc's waitcnt pass drain vmcnt(0) at the merge points of every iteration.
 #pragma unroll 1
     for (int x = ia; x <= xend; x++) {
+        if (p.prio == 1) march_prio((x ^ m.young) & 1);
         V3 nxt[9];
         march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);               // prefetch (last one: harmless re-load)
         const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
@@ -589,6 +598,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     int seam_col = -1;
 #pragma unroll 1
     for (int x = xs; x <= xend; x++) {
+        if (p.prio == 1) march_prio((x ^ m.young) & 1);
         V3 nxt[9];
         march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has3 = x - 3 >= ia;                                         // column x-3 is an output column
@@ -737,86 +747,6 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Ad
 #undef NONFAST
 #undef ALLSOLID
 #undef STEP1
-}
-
-template <typename T, int S, int DEPTH, bool EMIT, int FD>
-__global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
-{
-    constexpr int M3_WIN = 64 * S;
-    constexpr unsigned EB = sizeof(T);
-    const Geom &g = p.g;
-    const int lane = threadIdx.x & 63;
-    int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= p.nunits) return;
-    if (p.rev & 1) u = p.nunits - 1 - u;
-    const MarchUnit un = p.units[u];
-    const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
-    const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
-    if (ib <= ia) return;
-    const int row0 = w * M3_WIN;
-    const int j0 = row0 + lane * S;
-    const bool far_win = (w == 0) || (row0 + M3_WIN >= g.ny);
-    March3Addr<T, S> m;
-    MarchAddr<T, S> &a = m.a;
-    a.rs = march_rsrc(p.fs, p.lat_bytes);
-    a.rd = march_rsrc(p.fd, p.lat_bytes);
-    a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * EB));
-    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * EB;
-    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * EB : p.lat_bytes;
-    a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
-    a.lane = lane;
-    const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 8u * EB;
-    const __amdgpu_buffer_rsrc_t rh1 = march_rsrc(p.halo, hbytes), rh2 = march_rsrc(p.halo2, hbytes), rh3 = march_rsrc(p.halo3, hbytes);
-    unsigned hoff;
-    {
-        const int hl = lane < 6 ? lane : 0;
-        const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
-        const int slot = hl < 3 ? hl : hl + 1;
-        const int seam = hl < 3 ? w : w + 1;
-        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 8 + slot) * EB;
-    }
-    {
-        // per wave, in elements: below[40] (slot k = the window's last four rows of direction k, staged by the last 4/S lanes; slot
-        // 9 stays zero), above[40] (rows 0..3, the first 4/S lanes), then a scratch area for the other lanes' writes
-        constexpr int EDGE = 4 / S;                       // lanes that hold four rows
-        constexpr int NCH = 10 * (int)sizeof(T) / 4;      // 16-byte chunks of one half
-        __shared__ __attribute__((aligned(16))) T seam_lds[4][2 * M3_SHALF + 176];
-        T *wl = &seam_lds[threadIdx.x >> 6][0];
-        m.lds_w = lane >= 64 - EDGE ? wl + (lane - (64 - EDGE)) * S : (lane < EDGE ? wl + M3_SHALF + lane * S : wl + 2 * M3_SHALF + S * lane);
-        m.lds_r = reinterpret_cast<const char *>(wl) + 16 * (lane < NCH ? lane : 0);
-        if (lane < M3_SHALF) { wl[lane] = T(0); wl[lane + M3_SHALF] = T(0); }
-        const unsigned sbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * EB);
-        m.rs3 = march_rsrc(p.seams, sbytes);
-        const unsigned rec = (unsigned)(g.nxl + 2) * (unsigned)(M3_SREC * EB);
-        m.voff_lo = lane < NCH ? (unsigned)w * rec + (unsigned)(M3_SHALF * EB) + (unsigned)lane * 16u : sbytes;
-        m.voff_hi = lane < NCH ? (unsigned)(w + 1) * rec + (unsigned)lane * 16u : sbytes;
-    }
-    T feq0[9];
-    feq_all<T>(T(1), p.U0, T(0), feq0);
-
-    // classes of columns ia-PAD .. ib+PAD-1 (lane l <-> column ia-PAD+l): two 64-bit scalars
-    constexpr int PAD = DEPTH == 4 ? 3 : 2;
-    unsigned long long nonfast_m, solid_m;
-    {
-        const int n = ib - ia + 2 * PAD;
-        const int col = ia - PAD + lane;
-        uint8_t cls = WC_FAST;
-        if (lane < n && col >= -1 && col <= g.nxl) cls = p.wcls[(long)w * (g.nxl + 2) + col + 1];
-        nonfast_m = __ballot(cls != WC_FAST);
-        solid_m = __ballot(cls == WC_SOLID);
-    }
-    const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= PAD + 1 && ib + g.gi0 <= g.nx_g - PAD - 1 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
-    if (DEPTH == 4) {
-        constexpr int FDP = sizeof(T) == 4 ? (FD | MARCH_FD_PACKED) : FD;     // fp32: the packed two-site collision (step_march.hpp)
-        if (lean) march_unit4<false, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
-        else march_unit4<true, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
-    } else if (DEPTH == 3) {
-        if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
-        else march_unit3<true, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
-    } else {
-        if (lean) march_unit3_d2<false, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
-        else march_unit3_d2<true, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
-    }
 }
 
 // Marched column range of a three-step pass: global edges as in march_range; a local slab edge loses THREE columns of

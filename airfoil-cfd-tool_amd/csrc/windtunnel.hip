@@ -21,6 +21,7 @@
 #include "step_fast.hpp"
 #include "step_march.hpp"
 #include "step_march3.hpp"
+#include "step_chain.hpp"
 #ifndef WT_LOAD_AUX
 #define WT_LOAD_AUX 2
 #endif
@@ -126,6 +127,8 @@ struct wt_handle {
     float fd_tau = 0.0f;
     bool fd_checked = false, fd_ok = false;
     bool fast_div = true;                // option "fast_div"
+    bool chain = true;                   // option "chain": plain-fluid workgroups share their units' edge columns (step_chain.hpp)
+    int n_chain_units = 0;
 };
 
 static const int kReduceBlocks = 1024;
@@ -244,6 +247,8 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
         if (c && atoi(c) >= 0) h->fuse_chunk = atoi(c);
         const char *fdv = getenv("WT_FAST_DIV");
         if (fdv) h->fast_div = atoi(fdv) != 0;
+        const char *ch = getenv("WT_CHAIN");
+        if (ch) h->chain = atoi(ch) != 0;
     }
     *out = h;
     return WT_OK;
@@ -414,8 +419,25 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
 
     const MarchRange r = depth >= 3 ? march_range3(g, depth) : march_range(g);
     // four steps per pass: class masks cover ib - ia + 6 columns, and the last unit of a window marches at least two
-    const MarchPlan pl = build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, 2.0, &r, depth == 4 ? 2 : 1,
-                                          depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK);
+    // cost of a column that is not plain fluid, in plain columns: 1 + alpha; `over`: columns a unit iterates over beyond its own (pipeline
+    // fill and drain of a `depth`-step pass); `tail`: the outlet column's extra stages — see build_march_plan_timed
+    static const double alpha = getenv("WT_ALPHA") ? atof(getenv("WT_ALPHA")) : 2.2;
+    static const int timed = getenv("WT_PLAN_TIMED") ? atoi(getenv("WT_PLAN_TIMED")) : 1;
+    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
+    const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
+    const bool by_time = h->fuse_chunk <= 0 && timed;
+    const bool chain = depth >= 3 && h->chain;
+    // chain overheads in columns, from per-unit clocks on a 544-column lattice (tools/unit_clocks.py): a four-step chain unit of 8.5 columns takes as
+    // long as 10.5 solo iterations, a three-step one as 9.9
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4};
+    MarchPlan pl = !by_time ? build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, timed ? alpha : 4.0, &r, min_last, max_len, chain ? 4 : 1)
+                   : chain  ? build_chain_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, depth, cc)
+                            : build_march_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, over, tail);
+    h->n_chain_units = 0;
+    if (chain) {
+        if (!by_time) chain_blocks(pl, h->host_wcls.data(), g, depth, true);      // the fuse_chunk option: blocks of four consecutive units of the cut by columns
+        for (const MarchUnit &u : pl.units) h->n_chain_units += (u.flags & MU_CHAIN) != 0;
+    }
     const size_t total = pl.units.size();
     if (total == 0) return WT_OK;
     if (total > h->units_cap) {
@@ -469,10 +491,14 @@ static int rebuild_fuse_plan(wt_handle *h)
     const bool two_on_three = h->dtype != WT_F32 && h->fuse_depth == 2;  // fp64: two-step passes on the three-step tables
     const bool depth3_ok = h->g.nxl >= 16 && (h->fuse_depth != 2 || two_on_three);
     if (depth3_ok) {
-        // four steps per pass where the units are long (measured, same box: fp32 4096^2 154.2 -> 156.7 GLUPS, 2080 / 1056 / 544 columns
-        // 63.0 -> 63.9 / 36.7 -> 37.6 / 24.7 -> 25.2 us per step; fp64 4096^2 82.4 -> 87.9 GLUPS, 4096 x 2048 72.5 -> 75.5, 1056 columns +1 %)
+        // Steps per pass (round 3, tools/run_width_sweep.sh, us per step on 4096 rows, fp32, steps per pass 2 / 3 / 4): 288 columns 16.5 / 17.7 /
+        // 18.9; 416: 20.9 / 21.3 / 22.1; 544: 25.0 / 24.7 / 24.4; 800: 33.5 / 30.1 / 28.3; 1056: 41.4 / 36.8 / 33.5; 2080: - / 65.1 / 59.8; 4096: - /
+        // 114.3 / 96.7 — four steps per pass from eight columns per resident unit up, two below (the two-step kernel further down);
+        // fp64 (round 2): 4096^2 82.4 -> 87.9 GLUPS with four, 4096 x 2048 72.5 -> 75.5, 1056 columns +1 %, three below 24 columns per unit.
         const long tiles3 = (long)(h->g.nxl - 4) * march_nwin(h->g.ny, 64 * s3);
-        const int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (h->dtype == WT_F32 ? 48 : 24)) ? 4 : 3;
+        const bool f32 = h->dtype == WT_F32;
+        if (f32 && h->fuse_depth == 0 && !h->fuse_force && h->fuse_chunk <= 0 && tiles3 / slots < 8) goto two_step;
+        const int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (f32 ? 8 : 24)) ? 4 : 3;
         const MarchRange r = march_range3(h->g, depth);
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
         const bool force = h->fuse_force || h->fuse_depth >= 2;
@@ -486,6 +512,7 @@ static int rebuild_fuse_plan(wt_handle *h)
             return WT_OK;
         }
     }
+two_step:
     if (h->fuse_depth >= 3 || h->dtype != WT_F32) return WT_OK;
     // fp32, two steps per pass on 128-row windows (measured with 4096 rows: 288 columns = 4.5 per unit 16.6 us/step against 20.9 for
     // single steps and 18.5 for three steps per pass)
@@ -503,6 +530,18 @@ extern "C" int wt_debug_m3_stamps(unsigned long long *out, int reset)
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(wt::g_m3_stamps), 8 * sizeof(unsigned long long)));
     if (reset) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(wt::g_m3_stamps), z, sizeof(z))); }
     return WT_OK;
+}
+#endif
+
+#ifdef WT_UNIT_CLOCKS         // diagnostic build only (tools/unit_clocks.py); not part of the ABI
+extern "C" int wt_debug_unit_clocks(wt_handle *h, unsigned long long *clk, int *units4, int cap)
+{
+    WT_TRY(check_handle(h));
+    HIP_TRY(hipDeviceSynchronize());
+    const int n = h->n_units < cap ? h->n_units : cap;
+    HIP_TRY(hipMemcpyFromSymbol(clk, HIP_SYMBOL(wt::g_unit_clk), (size_t)2 * n * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpy(units4, h->d_units, (size_t)n * sizeof(MarchUnit), hipMemcpyDeviceToHost));
+    return n;
 }
 #endif
 
@@ -542,6 +581,10 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->fast_div = value != 0.0;
         return WT_OK;
     }
+    if (strcmp(name, "chain") == 0) {
+        h->chain = value != 0.0;
+        return rebuild_fuse_plan(h);
+    }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
 
@@ -557,6 +600,8 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "fuse_depth") == 0) { *value = h->fuse_ready ? eff_depth(h) : h->fuse_depth; return WT_OK; }
     if (strcmp(name, "fuse_tiles_general") == 0) { *value = h->nonfast_tiles; return WT_OK; }   // window-tiles that take the body paths
     if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "chain") == 0) { *value = h->chain ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "chain_units") == 0) { *value = h->fuse_ready ? h->n_chain_units : 0; return WT_OK; }     // units that run in chain blocks
     if (strcmp(name, "single_steps") == 0) { *value = (double)h->single_steps; return WT_OK; }   // whole steps taken by k_step since the last init / write_f
     if (strcmp(name, "passes") == 0) { *value = (double)h->passes; return WT_OK; }
     if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
@@ -826,6 +871,7 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)((h->steps_done >> 1) & 1);
+    p.prio = 0;
     {
         static const int rev_mode = getenv("WT_MARCH_REV") ? atoi(getenv("WT_MARCH_REV")) : 2;     // experiments: 0 / 1 = fixed order
         if (rev_mode == 0 || rev_mode == 1) p.rev = rev_mode;
@@ -881,6 +927,10 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)(h->passes & 1);
+    {
+        static const int prio_mode = getenv("WT_PRIO") ? atoi(getenv("WT_PRIO")) : 0;
+        p.prio = prio_mode;
+    }
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
         if (h->march_depth == 4) {      // the plan's tables are those of the four-step pass, whatever this pass advances

@@ -6,10 +6,10 @@
 #include <cstdlib>
 #include <vector>
 #include <random>
-#include "../airfoil-cfd-tool_amd/csrc/step_march3.hpp"
+#include "../airfoil-cfd-tool_amd/csrc/step_chain.hpp"
 using namespace wt;
 
-static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, int depth, long target, int max_cost, unsigned seed)
+static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, int depth, long target, int max_cost, unsigned seed, int timed = 1)
 {
     Geom g{};
     g.nxl = nxl; g.ny = ny; g.gi0 = gi0; g.nx_g = nx_g; g.pitch = (ny + 255) / 256 * 256; g.plane = (long)(nxl + 2) * g.pitch + 4352;
@@ -17,14 +17,48 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
     std::vector<uint8_t> wcls((size_t)nwin * ld, WC_FAST);
     std::mt19937 rng(seed);
     for (int w = 0; w < nwin; w++)
-        for (int x = 0; x < nxl; x++) { const unsigned r = rng() % 100; if (r < 6) wcls[(size_t)w * ld + x + 1] = r < 2 ? WC_SOLID : WC_GENERAL; }
+        for (int x = 0; x < nxl; x++) {     // a body-like cluster of non-FAST tiles in a third of the windows, a few stray ones elsewhere
+            const unsigned r = rng() % 1000;
+            const bool body = (w % 3 == 1) && x > nxl / 3 && x < nxl / 2;
+            if (body ? r < 600 : r < 2) wcls[(size_t)w * ld + x + 1] = r % 3 == 0 ? WC_SOLID : WC_GENERAL;
+        }
     const MarchRange r = depth >= 3 ? march_range3(g, depth) : march_range(g);
     const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
-    const MarchPlan pl = build_march_plan(wcls.data(), g, win, target, max_cost, 2.0, &r, min_last, max_len);
+    // max_cost > 0 (the fuse_chunk option): the cut by owned columns; otherwise the library's default, the cut by time
+    const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
+    const bool chain_timed = depth >= 3 && max_cost <= 0 && timed == 1;
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4};
+    MarchPlan pl = (max_cost > 0 || timed == 0) ? build_march_plan(wcls.data(), g, win, target, max_cost, 2.0, &r, min_last, max_len, depth >= 3 ? 4 : 1)
+                   : chain_timed                ? build_chain_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, depth, cc)
+                                                : build_march_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, over, tail);
     int bad = 0;
+    size_t n_chain = 0;
+    if (depth >= 3) {
+        // step_chain.hpp: whole blocks of four units of one window; chain flags on all four or none; a chain block is contiguous, plain
+        // fluid over its whole footprint, clear of the tunnel ends, and its units hold at least `depth` columns each
+        if (!chain_timed) chain_blocks(pl, wcls.data(), g, depth, true);
+        const int pad = depth == 4 ? 3 : 2;
+        if (pl.units.size() % 4) bad++;
+        for (size_t b = 0; b + 3 < pl.units.size(); b += 4) {
+            const MarchUnit *u = &pl.units[b];
+            int nc = 0;
+            for (int k = 0; k < 4; k++) nc += (u[k].flags & MU_CHAIN) != 0;
+            for (int k = 0; k < 4; k++) if ((nc || !chain_timed) && u[k].w != u[0].w) bad++;      // (solo groups of the cut by time may mix windows)
+            if (nc != 0 && nc != 4) { bad++; continue; }
+            if (!nc) { for (int k = 0; k < 4; k++) if (u[k].flags & (MU_DIR_NEG | MU_END_SHARED)) bad++; continue; }
+            n_chain += 4;
+            if ((u[0].flags & ~MU_CHAIN) != MU_DIR_NEG || (u[1].flags & ~MU_CHAIN) != MU_END_SHARED ||
+                (u[2].flags & ~MU_CHAIN) != (MU_DIR_NEG | MU_END_SHARED) || (u[3].flags & ~MU_CHAIN) != 0) bad++;
+            for (int k = 0; k < 4; k++) { if (u[k].ib - u[k].ia < depth + 1) bad++; if (k && u[k].ia != u[k - 1].ib) bad++; }
+            const int lo = u[0].ia - pad, hi = u[3].ib + pad;
+            if (lo < 0 || hi > nxl || lo + gi0 < 1 || hi + gi0 > nx_g - 1) { bad++; continue; }
+            for (int x = lo; x < hi; x++) if (wcls[(size_t)u[0].w * ld + x + 1] != WC_FAST) bad++;
+        }
+    }
     std::vector<int> cover((size_t)nwin * nxl, 0);
     std::vector<int> last_len(nwin, -1), n_outlet(nwin, 0);
     for (const MarchUnit &u : pl.units) {
+        if (depth >= 3 && u.ib == u.ia && u.flags == 0) continue;      // padding unit of a window's last block
         if (u.w < 0 || u.w >= nwin || u.ia < r.i_begin || u.ib > r.i_end || u.ib <= u.ia) { bad++; continue; }
         if (u.ib - u.ia > max_len + min_last - 1) bad++;      // a suppressed cut before a short last unit may add min_last - 1 columns
         for (int x = u.ia; x < u.ib; x++) cover[(size_t)u.w * nxl + x]++;
@@ -36,9 +70,13 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
         if (r.i_end - r.i_begin >= min_last && last_len[w] < min_last) bad++;
         if (n_outlet[w] != (r.outlet_after ? 1 : 0)) bad++;
     }
-    if (max_cost <= 0 && target >= nwin && pl.chunk < max_len && (long)pl.units.size() > target) bad++;      // whole rounds, unless the length cap forces more units
-    printf("%-28s nxl %5d ny %5d win %3d depth %d target %5ld max_cost %2d: %6zu units, chunk %2d  %s\n", name, nxl, ny, win, depth, target, max_cost,
-           pl.units.size(), pl.chunk, bad ? "FAIL" : "ok");
+    if (timed && max_cost <= 0) {       // the cut by time: at most `target` units before block padding (unless the length cap forces more)
+        size_t live = 0; for (const MarchUnit &u : pl.units) live += u.ib > u.ia;
+        if (target >= nwin && pl.chunk < max_len - 1 && (long)live > target) bad++;
+    }
+    if (max_cost <= 0 && target >= nwin && pl.chunk < max_len && (long)pl.units.size() > target + 3 * nwin) bad++;      // whole rounds (+ block padding), unless the length cap forces more units
+    printf("%-28s nxl %5d ny %5d win %3d depth %d target %5ld max_cost %2d: %6zu units (%zu in chain blocks), chunk %2d  %s\n", name, nxl, ny, win, depth, target, max_cost,
+           pl.units.size(), n_chain, pl.chunk, bad ? "FAIL" : "ok");
     return bad;
 }
 
@@ -57,6 +95,10 @@ int main()
         bad += check("narrow slab", 24, 1000, 64, 4096, win, depth, 2048, 0, 8);
         bad += check("fp64-like windows", 4096, 2048, 0, 4096, 64, depth, 6144, 0, 9);
         bad += check("long units", 16384, 256, 0, 16384, win, depth, 16, 0, 10);                    // cap-forced cuts
+        bad += check("whole lattice, by columns", 4096, 4096, 0, 4096, win, depth, 4096, 0, 11, 0);
+        bad += check("short window", 9, 300, 0, 9, win, depth, 2048, 0, 12);
+        bad += check("whole lattice, by time, solo", 4096, 4096, 0, 4096, win, depth, 4096, 0, 13, 2);
+        bad += check("middle slab, by time, solo", 544, 4096, 1760, 4096, win, depth, 2048, 0, 14, 2);
     }
     printf("%s\n", bad ? "PLAN CHECK FAILED" : "plan check passed");
     return bad ? 1 : 0;

@@ -264,7 +264,7 @@ def test_fuse_auto_only_where_it_pays(pkg):
         for e in (wide, slab, f64):
             e.set_mask(np.zeros((e.ny, e.nx_global), np.uint8)); e.init_equilibrium(0.06)
             assert e.get_option("fuse_active") == 1.0     # the default
-        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(4, 2), (3, 2), (4, 1)]
+        assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(4, 2), (4, 2), (4, 1)]
         for e in (wide, slab, f64):
             e.set_option("fuse_depth", 2)
         assert [(e.get_option("fuse_depth"), e.get_option("fuse_sites")) for e in (wide, slab, f64)] == [(2, 2), (2, 2), (2, 1)]
