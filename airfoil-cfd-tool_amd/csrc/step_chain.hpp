@@ -411,7 +411,9 @@ static inline void chain_blocks(MarchPlan &pl, const uint8_t *wcls, const Geom &
 // plain fluid and clear of the tunnel's ends; elsewhere solo units are cut by time as before.  A chain block counts four units, and the
 // smallest t whose plan has at most target_units units is found by bisection.  Units come out in chunk-major order with every aligned group
 // of four either one chain block or four solo units (the last solo group of the list is padded with empty units).
-struct ChainCost { double over, tail, ov_inner, ov_outer; };     // solo: columns iterated beyond the unit's own, outlet extra; chain: per-unit overheads in columns
+// solo: columns iterated beyond the unit's own, outlet extra, slow-down of a unit that runs the general loop (inlet / outlet / body in its footprint:
+// class tests and scalar branches per column), cost of an iteration on a column beyond the tunnel's end; chain: per-unit overheads in columns
+struct ChainCost { double over, tail, ov_inner, ov_outer, beta, outside; };
 static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &g, int win, long target_units, double alpha, const MarchRange &r, int min_last,
                                                int max_len, int depth, const ChainCost &cc)
 {
@@ -430,7 +432,7 @@ static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &
         double *Cw = &C[(size_t)w * (n + 1)];
         for (int k = 0; k < n; k++) {
             const int x = r.i_begin - E + k, gi = x + g.gi0;
-            double cost = 0.0;
+            double cost = cc.outside;
             if (gi >= 0 && gi < g.nx_g) cost = (x >= -1 && x <= g.nxl && c[x] != WC_FAST) ? 1.0 + alpha : 1.0;
             Cw[k + 1] = Cw[k] + cost;
         }
@@ -444,13 +446,14 @@ static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &
         const int k0 = (int)k;
         return k0 >= n ? Cw[n] : Cw[k0] + (k - k0) * (Cw[k0 + 1] - Cw[k0]);
     };
-    auto unit_time = [&](const double *Cw, int ia, int ib) {
-        return Cf(Cw, ib + cc.over / 2) - Cf(Cw, ia - cc.over / 2) + ((r.outlet_after && ib == r.i_end) ? cc.tail : 0.0);
-    };
     auto plain = [&](int w, int lo, int hi) {                  // columns [lo, hi) all FAST, inside the lattice and clear of the tunnel's ends
         if (lo < 0 || hi > g.nxl || lo + g.gi0 < 1 || hi + g.gi0 > g.nx_g - 1) return false;
         const int *Nw = &NF[(size_t)w * (g.nxl + 3)];
         return Nw[hi + 1] - Nw[lo + 1] == 0;
+    };
+    auto unit_time = [&](int w, const double *Cw, int ia, int ib) {
+        const double t0 = Cf(Cw, ib + cc.over / 2) - Cf(Cw, ia - cc.over / 2) + ((r.outlet_after && ib == r.i_end) ? cc.tail : 0.0);
+        return plain(w, ia - pad, ib + pad) ? t0 : cc.beta * t0;
     };
     struct Item { MarchUnit u[4]; int n; };                    // a chain block (n = 4) or one solo unit (n = 1)
     auto cut = [&](int w, double t, std::vector<Item> *out) {
@@ -476,9 +479,9 @@ static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &
             }
             int ib = ia + 1;
             const int cap = std::min(r.i_end, ia + max_len);
-            while (ib < cap && unit_time(Cw, ia, ib + 1) <= t) ib++;
+            while (ib < cap && unit_time(w, Cw, ia, ib + 1) <= t) ib++;
             if (r.i_end - ib > 0 && r.i_end - ib < min_last) {
-                if (r.i_end - min_last <= ia || (r.i_end - ia <= max_len + min_last - 1 && unit_time(Cw, ia, r.i_end) <= t)) ib = r.i_end;
+                if (r.i_end - min_last <= ia || (r.i_end - ia <= max_len + min_last - 1 && unit_time(w, Cw, ia, r.i_end) <= t)) ib = r.i_end;
                 else ib = r.i_end - min_last;
             }
             if (out) { Item it; it.n = 1; it.u[0] = MarchUnit{ia, ib, w, (r.outlet_after && ib == r.i_end) ? MU_OUTLET_AFTER : 0}; out->push_back(it); }

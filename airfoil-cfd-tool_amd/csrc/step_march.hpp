@@ -438,6 +438,23 @@ template <int S> __device__ __forceinline__ uint32_t load_site_bytes(const uint8
     else return *p;
 }
 
+// The solid flags and bounce codes of a lane's sites in one column do not depend on the level, and a unit's general loop needs them for
+// the same column at consecutive iterations (STEP_FS at x, the next level at x - 1, ...).  Fetched inside the stage that uses them they
+// sit behind a scalar branch, and hipcc's wait for them drains vmcnt to 0 — the prefetched column and the stores of the previous
+// iteration included: a round trip to memory per level and iteration (27 such waits in the four-step general loop; per-unit clocks: a body
+// column cost 3.2 plain ones).  Fetched ONE ITERATION AHEAD for every column of a general unit, beside the prefetched populations, and
+// handed down from level to level in registers, they cost two byte loads per iteration and no wait of their own.
+struct SiteBytes { uint32_t v[2]; };     // {solid4, code4}
+template <typename T, int S>
+__device__ __forceinline__ SiteBytes site_bytes_load(const MarchParams<T> &p, int col, int j0)
+{
+    const int c = col < 0 ? 0 : (col > p.g.nxl - 1 ? p.g.nxl - 1 : col);       // (columns outside carry no class: their bytes are never used)
+    SiteBytes r;
+    r.v[0] = load_site_bytes<S>(p.mask + (long)(c + 1) * p.g.pitch + j0);
+    r.v[1] = load_site_bytes<S>(p.bcode + (long)c * p.g.pitch + j0);
+    return r;
+}
+
 // Two fp32 sites per lane as 2-vectors: the operations of collide_head / collide_tail (d2q9.hpp), element for element, written
 // on float2 so that hipcc emits packed instructions (v_pk_add / v_pk_mul / v_pk_fma_f32) without the register-shuffling moves
 // its SLP vectoriser pays for the same pairs (a third of the loop's vector instructions go away).  Selected by bit 2 of FD
@@ -717,9 +734,10 @@ template <typename T> __device__ __forceinline__ T halo_load(__amdgpu_buffer_rsr
 }
 
 // Step 1 of column x -> G (all nine directions).  `in` holds the streamed inputs of column x (modified in place).
+// `pre` (optional): the column's solid flags and bounce codes {solid4, code4}, fetched ahead by the caller (SiteBytes below)
 template <bool BODY, int FD, typename T, int S>
 __device__ __forceinline__ void march_step1(const MarchParams<T> &p, const MarchAddr<T, S> &a, int x, int j0, bool far_win, bool nonfast, bool allsolid,
-                                            const T (&feq0)[9], MV<T, S> (&in)[9], MV<T, S> (&G)[9])
+                                            const T (&feq0)[9], MV<T, S> (&in)[9], MV<T, S> (&G)[9], const uint32_t *pre = nullptr)
 {
     MV<T, S> mac[3];
     if (BODY) {
@@ -730,8 +748,11 @@ __device__ __forceinline__ void march_step1(const MarchParams<T> &p, const March
             // rare paths (scalar branches): inlet / outlet columns, body surface, body interior
             uint32_t solid4 = 0, code4 = 0;
             if (nonfast) {
-                solid4 = load_site_bytes<S>(p.mask + (long)(x + 1) * g.pitch + j0);
-                code4 = load_site_bytes<S>(p.bcode + (long)x * g.pitch + j0);
+                if (pre) { solid4 = pre[0]; code4 = pre[1]; }
+                else {
+                    solid4 = load_site_bytes<S>(p.mask + (long)(x + 1) * g.pitch + j0);
+                    code4 = load_site_bytes<S>(p.bcode + (long)x * g.pitch + j0);
+                }
             }
             const bool any_solid = __ballot(solid4 != 0) != 0ULL;
             if (gi <= 0) {

@@ -320,7 +320,7 @@ struct March3Addr {
 template <bool BODY, bool WANT_MACRO, int FD, typename T, int S>
 __device__ __forceinline__ void march_stage(const MarchParams<T> &p, int c, int j0, int lane, bool far_win, bool nf, bool allsolid,
                                             const T (&feq0)[9], const MV<T, S> (&m158)[3], const MV<T, S> (&Gc)[9], const MV<T, S> (&Gn)[9], T hv,
-                                            MV<T, S> (&out)[9], MV<T, S> (&mac)[3])
+                                            MV<T, S> (&out)[9], MV<T, S> (&mac)[3], const uint32_t *pre = nullptr)
 {
     typedef MV<T, S> V3;
     const Geom &g = p.g;
@@ -336,8 +336,11 @@ __device__ __forceinline__ void march_stage(const MarchParams<T> &p, int c, int 
             auto ownc = [&](int k) { return Gc[k]; };
             uint32_t solid4 = 0, code4 = 0;
             if (nf) {
-                solid4 = load_site_bytes<S>(p.mask + (long)(c + 1) * g.pitch + j0);
-                code4 = load_site_bytes<S>(p.bcode + (long)c * g.pitch + j0);
+                if (pre) { solid4 = pre[0]; code4 = pre[1]; }
+                else {
+                    solid4 = load_site_bytes<S>(p.mask + (long)(c + 1) * g.pitch + j0);
+                    code4 = load_site_bytes<S>(p.bcode + (long)c * g.pitch + j0);
+                }
             }
             const bool any_solid = __ballot(solid4 != 0) != 0ULL;
             if (gi <= 0) {
@@ -397,6 +400,12 @@ __device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1 = T
     for (int k = 0; k < 9; k++) __builtin_memcpy(&r[k], &c[k], 8);
     asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(r[8]), "v"(h1), "v"(h2), "v"(h3));
 }
+__device__ __forceinline__ void wait_for_bytes(const SiteBytes &b)
+{
+#ifndef WT_M3_NOWAIT
+    asm volatile("" ::"v"(b.v[0]), "v"(b.v[1]));
+#endif
+}
 // ... and keep it from drifting upwards: an asm that reads the column about to be stored is ordered before the one above
 template <typename T, int S>
 __device__ __forceinline__ void pin_after(const MV<T, S> (&c)[9])
@@ -437,6 +446,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 #define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 2)) & 1ULL) != 0)
 #define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 2)) & 1ULL) != 0)
 #define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+#define STEP1P(x, in, G, sb) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, BODY ? (sb).v : nullptr)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
     const int xend = outlet ? ib : ib + 1;       // last column whose level 1 is computed (the outlet column itself for the last unit)
     V3 s1m[3], s1c[9];           // level 1: populations 1,5,8 of column x-2; all nine of column x-1
@@ -461,6 +471,9 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     // halo-table words of the columns the first iteration produces (fetched one iteration ahead, like the populations)
     T hv1 = halo_load<T>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);
     T hv2 = halo_load<T>(rh2, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * HREC);
+    // site bytes of columns x, x-1, x-2 (general loop only; see SiteBytes)
+    SiteBytes sb0{{0, 0}}, sb1{{0, 0}}, sb2{{0, 0}};
+    if (BODY) { sb0 = site_bytes_load<T, S>(p, ia, j0); sb1 = site_bytes_load<T, S>(p, ia - 1, j0); sb2 = site_bytes_load<T, S>(p, ia - 2, j0); wait_for_bytes(sb0); wait_for_bytes(sb1); wait_for_bytes(sb2); }
     wait_for_column(in, hv1, hv2);      // no load pending at the loop header: see wait_for_column
     int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
 #ifdef WT_M3_STAMPS
@@ -478,21 +491,24 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         const int c1 = x - 1, c2 = x - 2;
         const T hv1n = halo_load<T>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * HREC);
         const T hv2n = halo_load<T>(rh2, hoff, (unsigned)(c2 + 1 > 0 ? c2 + 1 : 0) * HREC);
+        SiteBytes sbn{{0, 0}};
+        if (BODY) sbn = site_bytes_load<T, S>(p, x + 1, j0);
         const Seam3 sp = seam3_fetch(m);                                       // staged by the previous iteration's store
         M3_STAMP(0);                                                           // issue of the prefetch
-        STEP1(x, in, G1);                                                      // level 1 of column x
+        STEP1P(x, in, G1, sb0);                                                // level 1 of column x
         M3_STAMP(1);
         // level 2 of column x-1 (a column left of the inlet takes the inlet branch: constants, no memory access)
-        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac);
+        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);
 #ifdef WT_M3_STAMPS
         pin_after(G2);
 #endif
         M3_STAMP(2);
         V3 out[9];
-        march_stage<BODY, EMIT, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, out, mac);
+        march_stage<BODY, EMIT, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, out, mac, BODY ? sb2.v : nullptr);
         pin_after(out);
         M3_STAMP(3);
         wait_for_column(nxt, hv1n, hv2n);
+        if (BODY) { wait_for_bytes(sbn); sb2 = sb1; sb1 = sb0; sb0 = sbn; }
 #ifdef WT_M3_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -550,6 +566,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 #undef NONFAST
 #undef ALLSOLID
 #undef STEP1
+#undef STEP1P
 }
 
 // FOUR steps per pass: one more level (s3m / s3c) and one more stage than march_unit3; the pipeline starts one column earlier
@@ -594,6 +611,12 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
 #define LCOL(x) ((BODY && (x) + g.gi0 < 0) ? -g.gi0 : (x))
     march_load_stream(a, LCOL(xs), in);
     T hv1 = halo_load<T>(rh1, hoff, HCOL(xs - 1)), hv2 = halo_load<T>(rh2, hoff, HCOL(xs - 2)), hv3 = halo_load<T>(rh3, hoff, HCOL(xs - 3));
+    // site bytes of columns x, x-1, x-2, x-3 (general loop only; see SiteBytes)
+    SiteBytes sb0{{0, 0}}, sb1{{0, 0}}, sb2{{0, 0}}, sb3{{0, 0}};
+    if (BODY) {
+        sb0 = site_bytes_load<T, S>(p, xs, j0); sb1 = site_bytes_load<T, S>(p, xs - 1, j0); sb2 = site_bytes_load<T, S>(p, xs - 2, j0); sb3 = site_bytes_load<T, S>(p, xs - 3, j0);
+        wait_for_bytes(sb0); wait_for_bytes(sb1); wait_for_bytes(sb2); wait_for_bytes(sb3);
+    }
     wait_for_column(in, hv1, hv2, hv3);
     int seam_col = -1;
 #pragma unroll 1
@@ -604,14 +627,17 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         const bool has3 = x - 3 >= ia;                                         // column x-3 is an output column
         const int c1 = x - 1, c2 = x - 2, c3 = x - 3;
         const T hv1n = halo_load<T>(rh1, hoff, HCOL(c1 + 1)), hv2n = halo_load<T>(rh2, hoff, HCOL(c2 + 1)), hv3n = halo_load<T>(rh3, hoff, HCOL(c3 + 1));
+        SiteBytes sbn{{0, 0}};
+        if (BODY) sbn = site_bytes_load<T, S>(p, x + 1, j0);
         const Seam3 sp = seam3_fetch(m);
-        STEP1(x, in, G1);                                                      // level 1 of column x
-        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac);     // level 2 of x-1
-        march_stage<BODY, false, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, G3, mac);     // level 3 of x-2
+        march_step1<BODY, FD, T, S>(p, a, x, j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G1, BODY ? sb0.v : nullptr);      // level 1 of column x
+        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);     // level 2 of x-1
+        march_stage<BODY, false, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, G3, mac, BODY ? sb2.v : nullptr);     // level 3 of x-2
         V3 out[9];
-        march_stage<BODY, EMIT, FD>(p, c3, j0, lane, far_win, NONFAST(c3), ALLSOLID(c3), feq0, s3m, s3c, G3, hv3, out, mac);     // level 4 of x-3
+        march_stage<BODY, EMIT, FD>(p, c3, j0, lane, far_win, NONFAST(c3), ALLSOLID(c3), feq0, s3m, s3c, G3, hv3, out, mac, BODY ? sb3.v : nullptr);     // level 4 of x-3
         pin_after(out);
         wait_for_column(nxt, hv1n, hv2n, hv3n);
+        if (BODY) { wait_for_bytes(sbn); sb3 = sb2; sb2 = sb1; sb1 = sb0; sb0 = sbn; }
         hv1 = hv1n; hv2 = hv2n; hv3 = hv3n;
         march3_store<EMIT>(m, has3 ? a.voff_st : p.lat_bytes, has3 ? c3 : 0, out, mac);
         seam3_flush(m, seam_col, sp);

@@ -421,7 +421,7 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     // four steps per pass: class masks cover ib - ia + 6 columns, and the last unit of a window marches at least two
     // cost of a column that is not plain fluid, in plain columns: 1 + alpha; `over`: columns a unit iterates over beyond its own (pipeline
     // fill and drain of a `depth`-step pass); `tail`: the outlet column's extra stages — see build_march_plan_timed
-    static const double alpha = getenv("WT_ALPHA") ? atof(getenv("WT_ALPHA")) : 2.2;
+    static const double alpha = getenv("WT_ALPHA") ? atof(getenv("WT_ALPHA")) : 1.6;
     static const int timed = getenv("WT_PLAN_TIMED") ? atoi(getenv("WT_PLAN_TIMED")) : 1;
     const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
     const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
@@ -429,7 +429,8 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     const bool chain = depth >= 3 && h->chain;
     // chain overheads in columns, from per-unit clocks on a 544-column lattice (tools/unit_clocks.py): a four-step chain unit of 8.5 columns takes as
     // long as 10.5 solo iterations, a three-step one as 9.9
-    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4};
+    static const double beta = getenv("WT_BETA") ? atof(getenv("WT_BETA")) : 1.25;
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, beta, 0.6};
     MarchPlan pl = !by_time ? build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, timed ? alpha : 4.0, &r, min_last, max_len, chain ? 4 : 1)
                    : chain  ? build_chain_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, depth, cc)
                             : build_march_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, over, tail);

@@ -27,7 +27,7 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
     // max_cost > 0 (the fuse_chunk option): the cut by owned columns; otherwise the library's default, the cut by time
     const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
     const bool chain_timed = depth >= 3 && max_cost <= 0 && timed == 1;
-    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4};
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, 1.25, 0.6};
     MarchPlan pl = (max_cost > 0 || timed == 0) ? build_march_plan(wcls.data(), g, win, target, max_cost, 2.0, &r, min_last, max_len, depth >= 3 ? 4 : 1)
                    : chain_timed                ? build_chain_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, depth, cc)
                                                 : build_march_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, over, tail);
