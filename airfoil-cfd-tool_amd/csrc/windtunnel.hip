@@ -102,6 +102,8 @@ struct wt_handle {
     int fuse_depth = 0;                  // option: steps per pass (0 = automatic; 2 or 3)
     int march_depth = 0;                 // steps per pass the plan's tables are built for (3 / 4: step_march3.hpp; 2: step_march.hpp)
     int pass_cap = 0;                    // longest pass actually taken on those tables (0 = march_depth): fp64 with fuse_depth = 2
+    int tau_cap = 0;                     // fp32, set per stepping call: 3 when the fast division by tau is not proved for this tau (IEEE division:
+                                         // the four-step kernel would spill registers and is not built for it), else 0
     void *halo2 = nullptr;               // depth 3 / 4: level-2 halo table
     void *halo3 = nullptr;               // depth 4: level-3 halo table
     long long passes = 0;
@@ -332,7 +334,12 @@ static bool fuse_eligible_s(const wt_handle *h, int sites)
     return h->g.ny % sites == 0 && h->g.nxl >= 8 && 9ULL * h->g.plane * eb < (1ULL << 32) - (1ULL << 20);
 }
 static bool fuse_eligible(const wt_handle *h) { return fuse_eligible_s(h, h->dtype == WT_F32 ? 2 : 1); }
-static inline int eff_depth(const wt_handle *h) { return h->pass_cap > 0 && h->pass_cap < h->march_depth ? h->pass_cap : h->march_depth; }
+static inline int plan_depth(const wt_handle *h) { return h->pass_cap > 0 && h->pass_cap < h->march_depth ? h->pass_cap : h->march_depth; }
+static inline int eff_depth(const wt_handle *h)
+{
+    const int d = plan_depth(h);
+    return h->tau_cap > 0 && h->tau_cap < d ? h->tau_cap : d;
+}
 
 static void free_march_tables(wt_handle *h)
 {
@@ -598,7 +605,7 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "fuse_chunk") == 0) { *value = h->fuse_ready ? h->fuse_chunk_used : h->fuse_chunk; return WT_OK; }
     if (strcmp(name, "fuse_units") == 0) { *value = h->n_units; return WT_OK; }
     if (strcmp(name, "fuse_sites") == 0) { *value = h->fuse_ready ? h->march_s : h->fuse_sites; return WT_OK; }
-    if (strcmp(name, "fuse_depth") == 0) { *value = h->fuse_ready ? eff_depth(h) : h->fuse_depth; return WT_OK; }
+    if (strcmp(name, "fuse_depth") == 0) { *value = h->fuse_ready ? plan_depth(h) : h->fuse_depth; return WT_OK; }
     if (strcmp(name, "fuse_tiles_general") == 0) { *value = h->nonfast_tiles; return WT_OK; }   // window-tiles that take the body paths
     if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "chain") == 0) { *value = h->chain ? 1.0 : 0.0; return WT_OK; }
@@ -742,13 +749,49 @@ static int exchange_rccl(wt_handle *h)
     return WT_OK;
 }
 
-// TR_LOCAL: pull the ghost columns from the peers' lattices with peer copies on MY comm stream.
-// The caller guarantees the peers' `cur` lattices are final (wt_step_group event-joins them).
+// TR_LOCAL: pull the ghost columns from the peers' lattices on MY comm stream — one copy kernel when the peer lives on the same
+// device (it shows up in a kernel trace beside the interior step kernel; 18 separate hipMemcpyPeerAsync calls on one device cost far
+// more than the data), peer copies when it does not.  The caller guarantees the peers' `cur` lattices are final (wt_step_group
+// event-joins them).
+struct GhostCopy {
+    const char *src[2];          // side 0: left ghosts <- left peer's last owned columns; side 1: right ghosts <- right peer's first owned columns
+    char *dst[2];
+    size_t src_plane[2], dst_plane;      // bytes between two populations
+    size_t bytes;                // per population and side
+};
+__global__ __launch_bounds__(256) void k_ghost_copy(GhostCopy c)
+{
+    const int k = blockIdx.y, side = blockIdx.z;
+    if (!c.src[side]) return;
+    const uint4 *s = reinterpret_cast<const uint4 *>(c.src[side] + (size_t)k * c.src_plane[side]);
+    uint4 *d = reinterpret_cast<uint4 *>(c.dst[side] + (size_t)k * c.dst_plane);
+    const size_t n = c.bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+
 static int exchange_local(wt_handle *h)
 {
     const size_t bytes = (size_t)h->halo * h->g.pitch * h->esz;
     if ((h->gl && !h->peer_l) || (h->gr && !h->peer_r))
         return fail(WT_ERR_STATE, "a neighbouring slab of this locally linked group has been destroyed");
+    const bool same_l = !h->gl || h->peer_l->device == h->device, same_r = !h->gr || h->peer_r->device == h->device;
+    if (same_l && same_r) {
+        GhostCopy c{};
+        c.bytes = bytes;
+        c.dst_plane = (size_t)h->g.plane * h->esz;
+        if (h->gl) {
+            wt_handle *p = h->peer_l;
+            c.src[0] = col_ptr(p, p->cur, 0, p->gl + p->width - p->halo); c.dst[0] = col_ptr(h, h->cur, 0, 0); c.src_plane[0] = (size_t)p->g.plane * p->esz;
+        }
+        if (h->gr) {
+            wt_handle *p = h->peer_r;
+            c.src[1] = col_ptr(p, p->cur, 0, p->gl); c.dst[1] = col_ptr(h, h->cur, 0, h->gl + h->width); c.src_plane[1] = (size_t)p->g.plane * p->esz;
+        }
+        const unsigned nb = (unsigned)std::min<size_t>(64, (bytes / 16 + 255) / 256);
+        hipLaunchKernelGGL(k_ghost_copy, dim3(nb ? nb : 1, 9, 2), dim3(256), 0, h->s_comm, c);
+        HIP_TRY(hipGetLastError());
+        return WT_OK;
+    }
     for (int k = 0; k < 9; k++) {
         if (h->gl) {
             wt_handle *p = h->peer_l;
@@ -949,7 +992,9 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     if (p.nunits > 0) {
         const dim3 grid((unsigned)((p.nunits + 3) / 4));
         if (depth == 4) {
-            if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
+            // (fp32 with the IEEE division by tau: not built — 40-80 bytes of scratch per lane; set_tau_cap keeps such a call at three steps per pass)
+            if constexpr (sizeof(T) == 4 && FD == 0) return fail(WT_ERR_STATE, "internal: four-step pass with the IEEE division");
+            else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
         } else if (depth == 3) {
             if (emit) hipLaunchKernelGGL((k_march3<T, S, 3, true, FD>), grid, dim3(256), 0, st, p);
@@ -1000,8 +1045,21 @@ static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
     return step_pair_fused(h, tau, u0, emit);
 }
 
+// fp32 plans of depth 4 take three-step passes while the division by tau has to be the IEEE one (fast_div off, or a tau the proof rejects)
+static int set_tau_cap(wt_handle *h, double tau)
+{
+    h->tau_cap = 0;
+    if (h->fuse_ready && h->dtype == WT_F32 && h->march_depth == 4) {
+        bool fd = false;
+        WT_TRY(fastdiv_for(h, (float)tau, &fd));
+        if (!fd) h->tau_cap = 3;
+    }
+    return WT_OK;
+}
+
 static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
 {
+    WT_TRY(set_tau_cap(h, tau));
     int s = 0;
     while (s < nsteps) {
         const int k = fuse_stride(h, nsteps - s);
@@ -1149,6 +1207,10 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
         if (n > 1 && hs[r]->transport != TR_LOCAL) return fail(WT_ERR_STATE, "handle %d is not locally linked", r);
         if (hs[r]->ghost_valid != hs[0]->ghost_valid || hs[r]->steps_done != hs[0]->steps_done)
             return fail(WT_ERR_STATE, "slabs are not at the same step");
+    }
+    for (int r = 0; r < n; r++) {
+        HIP_TRY(hipSetDevice(hs[r]->device));
+        WT_TRY(set_tau_cap(hs[r], tau));
     }
     int s = 0;
     while (s < nsteps) {

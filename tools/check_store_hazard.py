@@ -77,6 +77,19 @@ def check(path):
     return nstores, bad
 
 
+RES = re.compile(r"^\s*\.set\s+(\S+)\.(num_vgpr|private_seg_size),\s*(\d+)")
+
+
+def resources(path):
+    """{kernel symbol: {"num_vgpr": n, "private_seg_size": bytes of scratch per lane}} from the .set lines of a gfx950 .s file."""
+    out = {}
+    for l in open(path):
+        m = RES.match(l)
+        if m:
+            out.setdefault(m.group(1), {})[m.group(2)] = int(m.group(3))
+    return out
+
+
 def build():
     tmp = tempfile.mkdtemp(prefix="wt_isa_")
     src = os.path.join(ROOT, "airfoil-cfd-tool_amd", "csrc", "windtunnel.hip")
