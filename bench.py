@@ -387,7 +387,7 @@ def main():
                 "fuse_depth": steps_per_launch if fused else 0,
                 "fast_div": int(eng.get_option("fast_div_active")) if fused else 0,
                 "single_steps": int(eng.get_option("single_steps"))}
-    # what the SQ counters say limits the kernel (profiles/r03_a_sq_counters_bench_kernel.txt): the marching kernels keep the vector ALU
+    # what the SQ counters say limits the kernel (profiles/r03_c_sq_counters_bench_kernel.txt): the marching kernels keep the vector ALU
     # busy for 60-70 % of their run time with two waves per SIMD while moving 45-50 % of the HBM peak; k_step is HBM-bound.
     roofline = {"bound": "valu" if fused else "hbm", "kernel": main_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": None if achieved is None else achieved / HBM_PEAK_GBPS,
