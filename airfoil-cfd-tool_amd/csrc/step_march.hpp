@@ -62,10 +62,12 @@ enum : uint8_t { WC_FAST = 0, WC_GENERAL = 1, WC_SOLID = 2 };
 static inline int march_nwin(int ny, int win) { return (ny + win - 1) / win; }
 
 // collision for either element type: fp32 with the division selected by FD (d2q9.hpp), fp64 always IEEE
+static constexpr int MARCH_FD_CONTRACTED = 8;    // bit 3 of FD: the opt-in contracted collision (d2q9.hpp collide_contracted; fp32 only)
 template <typename T, int FD>
 __device__ __forceinline__ void collide_t(const T (&fin)[9], const FastDiv &fdv, T tau, T (&fo)[9], T &rho, T &ux, T &uy)
 {
-    if constexpr (sizeof(T) == 4) collide_fd<(FD & 3)>(fin, fdv, fo, rho, ux, uy);
+    if constexpr (sizeof(T) == 4 && (FD & MARCH_FD_CONTRACTED) != 0) collide_contracted(fin, fdv.rtau, fo, rho, ux, uy);
+    else if constexpr (sizeof(T) == 4) collide_fd<(FD & 3)>(fin, fdv, fo, rho, ux, uy);
     else collide<T>(fin, tau, fo, rho, ux, uy);
 }
 
@@ -535,7 +537,18 @@ __device__ __forceinline__ void march_collide_sites(const MV<T, S> (&fin)[9], co
                                                     MV<T, S> &uy4)
 {
     constexpr int FDV = FD & 3;          // how to divide by tau (d2q9.hpp)
-    if constexpr (sizeof(T) == 4 && S == 2 && (FD & MARCH_FD_PACKED) != 0) {
+    if constexpr (sizeof(T) == 4 && (FD & MARCH_FD_CONTRACTED) != 0) {
+#pragma unroll
+        for (int v = 0; v < S; v++) {
+            float a[9], f[9], r, u, w;
+#pragma unroll
+            for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
+            collide_contracted(a, fdv.rtau, f, r, u, w);
+#pragma unroll
+            for (int k = 0; k < 9; k++) o[k].v[v] = f[k];
+            rho4.v[v] = r; ux4.v[v] = u; uy4.v[v] = w;
+        }
+    } else if constexpr (sizeof(T) == 4 && S == 2 && (FD & MARCH_FD_PACKED) != 0) {
         f2v a[9], f[9], r, u, w;
 #pragma unroll
         for (int k = 0; k < 9; k++) a[k] = f2v{fin[k].v[0], fin[k].v[1]};

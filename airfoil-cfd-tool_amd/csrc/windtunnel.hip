@@ -129,6 +129,7 @@ struct wt_handle {
     float fd_tau = 0.0f;
     bool fd_checked = false, fd_ok = false;
     bool fast_div = true;                // option "fast_div"
+    bool fast_math = false;              // option "fast_math": contracted collision in the marching kernels (opt-in; tolerance, not bit-equality)
     bool chain = true;                   // option "chain": plain-fluid workgroups share their units' edge columns (step_chain.hpp)
     int n_chain_units = 0;
 };
@@ -593,6 +594,11 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->chain = value != 0.0;
         return rebuild_fuse_plan(h);
     }
+    if (strcmp(name, "fast_math") == 0) {
+        if (value != 0.0 && h->dtype != WT_F32) return fail(WT_ERR_STATE, "fast_math is an fp32 option");
+        h->fast_math = value != 0.0;
+        return WT_OK;
+    }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
 
@@ -609,6 +615,7 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "fuse_tiles_general") == 0) { *value = h->nonfast_tiles; return WT_OK; }   // window-tiles that take the body paths
     if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "chain") == 0) { *value = h->chain ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "fast_math") == 0) { *value = h->fast_math ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "chain_units") == 0) { *value = h->fuse_ready ? h->n_chain_units : 0; return WT_OK; }     // units that run in chain blocks
     if (strcmp(name, "single_steps") == 0) { *value = (double)h->single_steps; return WT_OK; }   // whole steps taken by k_step since the last init / write_f
     if (strcmp(name, "passes") == 0) { *value = (double)h->passes; return WT_OK; }
@@ -946,6 +953,7 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
 static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
 {
     if (h->dtype != WT_F32 || h->march_s != 2) return fail(WT_ERR_STATE, "internal: the two-step kernel runs fp32 handles with 2 sites per lane only");
+    if (h->fast_math) return step_pair_fused_t<float, 2, MARCH_FD_CONTRACTED>(h, tau, u0, emit);
     bool fd = false;
     WT_TRY(fastdiv_for(h, (float)tau, &fd));
     return fd ? step_pair_fused_t<float, 2, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 2, 0>(h, tau, u0, emit);
@@ -1038,6 +1046,7 @@ static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
 {
     if (h->march_depth >= 3) {
         if (h->dtype != WT_F32) return step_triple_fused_t<double, 1, 0>(h, tau, u0, emit, k);
+        if (h->fast_math) return step_triple_fused_t<float, 2, MARCH_FD_CONTRACTED>(h, tau, u0, emit, k);
         bool fd = false;
         WT_TRY(fastdiv_for(h, (float)tau, &fd));
         return fd ? step_triple_fused_t<float, 2, 1>(h, tau, u0, emit, k) : step_triple_fused_t<float, 2, 0>(h, tau, u0, emit, k);
@@ -1049,7 +1058,7 @@ static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
 static int set_tau_cap(wt_handle *h, double tau)
 {
     h->tau_cap = 0;
-    if (h->fuse_ready && h->dtype == WT_F32 && h->march_depth == 4) {
+    if (h->fuse_ready && h->dtype == WT_F32 && h->march_depth == 4 && !h->fast_math) {
         bool fd = false;
         WT_TRY(fastdiv_for(h, (float)tau, &fd));
         if (!fd) h->tau_cap = 3;

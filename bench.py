@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--fuse-chunk", type=int, default=0, help="cost limit of a marching unit in columns (0 = whole resident rounds)")
     ap.add_argument("--fuse-sites", type=int, default=0, choices=[0, 2, 4], help="sites per lane of the marching kernel (0 = automatic)")
     ap.add_argument("--fuse-depth", type=int, default=0, choices=[0, 2, 3, 4], help="steps per pass of the marching kernel (0 = automatic)")
+    ap.add_argument("--fast-math", type=int, default=-1, choices=[-1, 0, 1],
+                    help="the OPT-IN contracted collision (fused multiply-adds, v_rcp): -1 (default) = the bit-exact kernels print the line and the "
+                         "contracted ones are timed beside them as roofline.contracted; 0 = skip that; 1 = the whole run uses them (NOT bit-exact)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -314,6 +317,8 @@ def main():
             eng.set_option("fuse_depth", args.fuse_depth)
         if args.fuse >= 0:
             eng.set_option("fuse_steps", args.fuse)
+        if args.fast_math == 1:
+            eng.set_option("fast_math", 1)
         if distributed:
             # 2. the library's own communicator (beside torch's): unique id through torch.distributed, join under a watchdog
             ids = [wtpkg.Engine.comm_unique_id() if rank == 0 else None]
@@ -400,6 +405,20 @@ def main():
                 "effective_gbps": r["effective_gbps"], "effective_frac": r["effective_frac"],
                 "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "launch_ms": launch_ms,
                 "steps_per_launch": steps_per_launch}
+    if fused and not distributed and args.fast_math == -1 and args.dtype == "float32":
+        # the opt-in contracted collision beside the bit-exact default, same run (tolerance-tested, tests/test_gpu_fast_math.py; never the default)
+        try:
+            eng.set_option("fast_math", 1)
+            eng.step(2 * steps_per_launch, args.tau, args.u0)
+            nfm = max(steps_per_launch, (min(args.steps, 200) // steps_per_launch) * steps_per_launch)
+            msf = eng.step_timed(nfm, args.tau, args.u0) / nfm
+            eng.set_option("fast_math", 0)
+            roofline["contracted"] = {"option": "fast_math = 1 (fused multiply-adds, v_rcp / v_rsq: within |d rho| <= 1e-5, |d u| <= 5e-6 of the oracle, not bit-exact)",
+                                      "ms_per_step": msf, "mlups": sites / (msf * 1e-3) / 1e6,
+                                      "gain_over_default": (dev_ms / args.steps) / msf,
+                                      "compulsory_frac": bpl * sites_per_launch / (msf * steps_per_launch * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        except Exception as e:      # noqa: BLE001
+            roofline["contracted"] = {"error": str(e)}
     if fused and not distributed:
         # the un-fused kernel beside it, same run, same lattice state
         try:
@@ -430,7 +449,7 @@ def main():
         "dtype": "f32" if args.dtype == "float32" else "f64",
         "data": "synthetic",
         "config": {"workload": workload, "nx": nx_total, "ny": ny, "slabs": world,
-                   "halo": args.halo if distributed else 0, **cfg_fuse,
+                   "halo": args.halo if distributed else 0, **cfg_fuse, "fast_math": int(args.fast_math == 1),
                    "solid_sites": int((mask != 0).sum())},
         "device_ms": per_rank_ms,
         "roofline": roofline,
