@@ -413,7 +413,7 @@ static inline void chain_blocks(MarchPlan &pl, const uint8_t *wcls, const Geom &
 // of four either one chain block or four solo units (the last solo group of the list is padded with empty units).
 // solo: columns iterated beyond the unit's own, outlet extra, slow-down of a unit that runs the general loop (inlet / outlet / body in its footprint:
 // class tests and scalar branches per column), cost of an iteration on a column beyond the tunnel's end; chain: per-unit overheads in columns
-struct ChainCost { double over, tail, ov_inner, ov_outer, beta, outside; };
+struct ChainCost { double over, tail, ov_inner, ov_outer, beta, outside; int max_chain; };
 static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &g, int win, long target_units, double alpha, const MarchRange &r, int min_last,
                                                int max_len, int depth, const ChainCost &cc)
 {
@@ -458,7 +458,8 @@ static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &
     struct Item { MarchUnit u[4]; int n; };                    // a chain block (n = 4) or one solo unit (n = 1)
     auto cut = [&](int w, double t, std::vector<Item> *out) {
         const double *Cw = &C[(size_t)w * (n + 1)];
-        const int Li = std::min((int)(t - cc.ov_inner), max_len), Lo = std::min((int)(t - cc.ov_outer), max_len);
+        // (chain units read no class masks: their length is not bound by the 64-bit masks of the solo units)
+        const int Li = std::min((int)(t - cc.ov_inner), cc.max_chain), Lo = std::min((int)(t - cc.ov_outer), cc.max_chain);
         const int B = 2 * Li + 2 * Lo;
         int ia = r.i_begin;
         long count = 0;
@@ -491,7 +492,7 @@ static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &
         return count;
     };
     auto total = [&](double t) { long s = 0; for (int w = 0; w < nwin; w++) s += cut(w, t, nullptr); return s; };
-    double lo = 0.0, hi = (double)max_len * (1.0 + alpha) + cc.over * (1.0 + alpha) + cc.tail + cc.ov_inner + 1.0;
+    double lo = 0.0, hi = (double)std::max(max_len, cc.max_chain) * (1.0 + alpha) + cc.over * (1.0 + alpha) + cc.tail + cc.ov_inner + 1.0;
     if (total(hi) > target_units) lo = hi;
     else {
         // the count is not monotonic in t where a block starts or stops fitting, so scan downwards from a bisection estimate

@@ -438,7 +438,8 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     // chain overheads in columns, from per-unit clocks on a 544-column lattice (tools/unit_clocks.py): a four-step chain unit of 8.5 columns takes as
     // long as 10.5 solo iterations, a three-step one as 9.9
     static const double beta = getenv("WT_BETA") ? atof(getenv("WT_BETA")) : 1.25;
-    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, beta, 0.6};
+    static const int max_chain = getenv("WT_MAX_CHAIN") ? atoi(getenv("WT_MAX_CHAIN")) : 160;
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, beta, 0.6, max_chain};
     MarchPlan pl = !by_time ? build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, timed ? alpha : 4.0, &r, min_last, max_len, chain ? 4 : 1)
                    : chain  ? build_chain_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, depth, cc)
                             : build_march_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, over, tail);
@@ -512,9 +513,14 @@ static int rebuild_fuse_plan(wt_handle *h)
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
         const bool force = h->fuse_force || h->fuse_depth >= 2;
         if (force || h->fuse_chunk > 0 || tiles / slots >= 6) {
-            long target = 2 * slots;
+            // ONE resident round of units with chain blocks (their units can be as long as the lattice asks for; tools/r3_rounds.sh: 2080 columns 52.9
+            // against 55.8 us per step with two rounds of half the length, 3000^2 56.7 / 60.5, 4096^2 90.4 / 92.9); without them two rounds
+            // where that leaves at least 12 columns per unit, as in round 2
+            long target = h->chain && h->fuse_chunk <= 0 ? slots : 2 * slots;
             if (tiles / target < 12) target = slots;
-            while (tiles / target > MARCH_MAX_CHUNK - 6) target += slots;     // a unit holds at most MARCH_MAX_CHUNK columns: more rounds
+            if (const char *e = getenv("WT_MARCH_ROUNDS")) { if (atoi(e) > 0) target = atoi(e) * slots; }      // experiments
+            if (!h->chain || h->fuse_chunk > 0)
+                while (tiles / target > MARCH_MAX_CHUNK - 6) target += slots;     // a solo unit holds at most MARCH_MAX_CHUNK columns: more rounds
             WT_TRY(build_fuse_plan(h, s3, target, depth));
             h->fuse_ready = h->n_units > 0;
             h->pass_cap = two_on_three ? 2 : 0;

@@ -5,9 +5,13 @@
 function's name and inputs and renders the MI355X tunnel instead: the component's own controls
 (html:20-58: angle of attack, field, flow speed, trails), the read-outs of html:53-57 (CL, CD,
 Reynolds, separation) and the composited canvas (compose.py).  Like the page's requestAnimationFrame
-loop (html:902-930) the image keeps advancing WITHOUT a user action: one call streams `frames` canvas
-updates into an ``st.empty()`` placeholder (and the four read-outs into theirs), `frames_per_update`
-simulation frames apart; a widget change reruns the script, which picks the same tunnel up again.
+loop (html:902-930, which never stops) the image keeps advancing WITHOUT a user action and WITHOUT an end:
+where the installed Streamlit has ``st.fragment`` the controls and the canvas live in a fragment that
+Streamlit re-runs every `run_every` seconds, for ever, each run advancing `frames_per_update` simulation
+frames (a control change re-runs just that fragment and is picked up by the next update); older Streamlit
+versions get a loop that streams updates into ``st.empty()`` placeholders until Streamlit stops the script
+(a widget change or the end of the session — the rerun then picks the same tunnel up again).  `frames=N`
+bounds the stream for batch use and tests.
 
 ``streamlit`` is imported lazily (it is not installed in the build image); everything else is the
 package's ordinary host API, so a page needs only::
@@ -44,9 +48,10 @@ def _tunnel_for(st, coords_after, airfoil_name: str, nx: int, ny: int, dtype: st
 
 
 def build_lbm_component(coords_after, airfoil_name: str = "", *, nx: int = 1024, ny: int = 512,
-                        dtype: str = "float32", frames: int = 240, frames_per_update: int = 4, scale: int = 1,
-                        st=None) -> Optional[WindTunnel]:
-    """Render the interactive LBM wind tunnel for the user's parsed coordinates (AA.py:20-42) and stream it live."""
+                        dtype: str = "float32", frames: Optional[int] = None, frames_per_update: int = 4, scale: int = 1,
+                        run_every: float = 0.05, st=None) -> Optional[WindTunnel]:
+    """Render the interactive LBM wind tunnel for the user's parsed coordinates (AA.py:20-42) and stream it live —
+    without an end unless `frames` bounds the stream (see the module text)."""
     if st is None:
         import streamlit as st          # noqa: PLC0415  (lazy: absent in the build image)
     try:
@@ -55,29 +60,34 @@ def build_lbm_component(coords_after, airfoil_name: str = "", *, nx: int = 1024,
         st.error(f"⚠️ LBM wind tunnel unavailable: {exc}")
         return None
 
-    aoa = st.slider("Angle of attack", -20.0, 25.0, 6.0, 0.5)                       # html:26
-    field = _FIELD_LABELS[st.selectbox("Field", list(_FIELD_LABELS))]              # html:32-36
-    u0 = st.slider("Flow speed", 30, 100, 60, 2) / 1000.0                           # html:41, 957
-    ntrails = st.slider("Trails", 800, 5000, 2600, 100)                             # html:47
-    if aoa != wt.aoa_deg:
-        wt.aoa_deg = aoa
-    wt.set_field(field)
-    wt.set_flow_speed(u0)
+    def controls():
+        """The component's own controls (html:20-58) -> the tunnel; Streamlit evaluates them once per (fragment) run."""
+        aoa = st.slider("Angle of attack", -20.0, 25.0, 6.0, 0.5)                   # html:26
+        field = _FIELD_LABELS[st.selectbox("Field", list(_FIELD_LABELS))]          # html:32-36
+        u0 = st.slider("Flow speed", 30, 100, 60, 2) / 1000.0                       # html:41, 957
+        ntrails = st.slider("Trails", 800, 5000, 2600, 100)                         # html:47
+        if aoa != wt.aoa_deg:
+            wt.aoa_deg = aoa
+        wt.set_field(field)
+        wt.set_flow_speed(u0)
+        tracers = st.session_state.get("wt_amd_tracers")
+        if tracers is None:
+            tracers = st.session_state["wt_amd_tracers"] = Tracers(wt, n=ntrails)
+        elif tracers.x.size != ntrails:
+            tracers.resize(ntrails)
+        layer = st.session_state.get("wt_amd_trails")
+        if layer is None or layer.s != scale:
+            layer = st.session_state["wt_amd_trails"] = TrailLayer(scale)
+        canvas = st.empty()                                                          # the <canvas> of the component
+        slots = [c.empty() for c in st.columns(4)]
+        return tracers, layer, canvas, slots
 
-    tracers = st.session_state.get("wt_amd_tracers")
-    if tracers is None:
-        tracers = st.session_state["wt_amd_tracers"] = Tracers(wt, n=ntrails)
-    elif tracers.x.size != ntrails:
-        tracers.resize(ntrails)
-    layer = st.session_state.get("wt_amd_trails")
-    if layer is None or layer.s != scale:
-        layer = st.session_state["wt_amd_trails"] = TrailLayer(scale)
-
-    canvas = st.empty()                                                              # the <canvas> of the component
-    c1, c2, c3, c4 = st.columns(4)
-    slots = [c.empty() for c in (c1, c2, c3, c4)]
-
-    def show():
+    def advance_and_show(tracers, layer, canvas, slots):
+        """`frames_per_update` passes of frame() (html:902-930), then one redraw of the canvas and the read-outs."""
+        for _ in range(max(1, int(frames_per_update))):
+            wt.frame(render=False)                                                   # 4 steps, ranges, forces every 3rd frame
+            tracers.draw(layer, 16.0)                                                # stepParticles(dt), html:917
+        st.session_state["wt_amd_frames"] = st.session_state.get("wt_amd_frames", 0) + max(1, int(frames_per_update))
         canvas.image(wt.compose_frame(trails=layer, scale=scale), caption="D2Q9 lattice-Boltzmann · MI355X · live unsteady solve",
                      use_column_width=True)
         s = wt.stats()                                                               # updateStatsUI, html:862-885
@@ -86,12 +96,19 @@ def build_lbm_component(coords_after, airfoil_name: str = "", *, nx: int = 1024,
         slots[2].metric("Reynolds", f"{round(s.reynolds):,}")
         slots[3].metric("Separation", s.separation)
 
-    done = 0
-    while done < int(frames):                                                        # the rAF loop, html:902-930
-        for _ in range(max(1, int(frames_per_update))):
-            wt.frame(render=False)                                                   # 4 steps, ranges, forces every 3rd frame
-            tracers.draw(layer, 16.0)                                                # stepParticles(dt), html:917
-            done += 1
-        show()
-    st.session_state["wt_amd_frames"] = st.session_state.get("wt_amd_frames", 0) + done
+    if frames is not None:                                                           # bounded stream (batch use, tests)
+        state = controls()
+        done = 0
+        while done < int(frames):
+            advance_and_show(*state)
+            done += max(1, int(frames_per_update))
+    elif hasattr(st, "fragment"):                                                    # Streamlit >= 1.33: re-run by Streamlit's own timer, for ever
+        @st.fragment(run_every=run_every)
+        def live():
+            advance_and_show(*controls())
+        live()
+    else:                                                                            # the rAF loop itself: ends only when Streamlit stops the script
+        state = controls()
+        while True:
+            advance_and_show(*state)
     return wt

@@ -27,7 +27,7 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
     // max_cost > 0 (the fuse_chunk option): the cut by owned columns; otherwise the library's default, the cut by time
     const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
     const bool chain_timed = depth >= 3 && max_cost <= 0 && timed == 1;
-    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, 1.25, 0.6};
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, 1.25, 0.6, 160};
     MarchPlan pl = (max_cost > 0 || timed == 0) ? build_march_plan(wcls.data(), g, win, target, max_cost, 2.0, &r, min_last, max_len, depth >= 3 ? 4 : 1)
                    : chain_timed                ? build_chain_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, depth, cc)
                                                 : build_march_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, over, tail);
@@ -60,7 +60,7 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
     for (const MarchUnit &u : pl.units) {
         if (depth >= 3 && u.ib == u.ia && u.flags == 0) continue;      // padding unit of a window's last block
         if (u.w < 0 || u.w >= nwin || u.ia < r.i_begin || u.ib > r.i_end || u.ib <= u.ia) { bad++; continue; }
-        if (u.ib - u.ia > max_len + min_last - 1) bad++;      // a suppressed cut before a short last unit may add min_last - 1 columns
+        if (u.ib - u.ia > ((u.flags & MU_CHAIN) ? 160 : max_len + min_last - 1)) bad++;      // a suppressed cut before a short last unit may add min_last - 1 columns
         for (int x = u.ia; x < u.ib; x++) cover[(size_t)u.w * nxl + x]++;
         if (u.ib == r.i_end) last_len[u.w] = u.ib - u.ia;
         if (u.flags & MU_OUTLET_AFTER) { n_outlet[u.w]++; if (u.ib != r.i_end || !r.outlet_after) bad++; }

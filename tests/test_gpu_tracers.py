@@ -102,6 +102,61 @@ def test_streamlit_page_streams_frames_without_a_rerun(pkg):
         wt.close()
 
 
+class _StopScript(Exception):
+    """What Streamlit does to a running script when a widget changes or the session ends."""
+
+
+def test_streamlit_page_never_stops_by_itself_and_picks_up_control_changes(pkg):
+    """f4, the stream without an end (html:902-930: the rAF loop never stops).  (1) A Streamlit without st.fragment: the call keeps
+    streaming until Streamlit itself stops the script — here after 7 canvas updates; with `frames` unset it would otherwise never
+    return.  (2) A Streamlit with st.fragment: the controls and the canvas live in a fragment that Streamlit re-runs on its timer;
+    a slider moved between two runs reaches the tunnel at the next update."""
+    from airfoil_cfd_tool_amd.streamlit_page import build_lbm_component
+    coords = pkg.geometry.SHAPES["naca2412"]()
+
+    class Old(_FakeStreamlit):
+        def image(self, img, caption=None, use_column_width=None):
+            super().image(img, caption, use_column_width)
+            if len([c for c in self.calls if c[0] == "image"]) == 7:
+                raise _StopScript()
+
+    st = Old()
+    with pytest.raises(_StopScript):
+        build_lbm_component(coords, "NACA 2412", nx=256, ny=128, frames_per_update=2, st=st)
+    wt = st.session_state["wt_amd_tunnel"]
+    try:
+        assert wt.steps == 7 * 2 * 4 and st.session_state["wt_amd_frames"] == 14      # 7 updates went out; nothing but the stop ended the stream
+
+        class New(_FakeStreamlit):
+            def __init__(self, session):
+                super().__init__()
+                self.session_state = session
+                self.aoa = 8.0
+                self.timer_runs = 0
+
+            def slider(self, label, lo, hi, value, step):
+                return self.aoa if label == "Angle of attack" else value
+
+            def fragment(self, run_every=None):
+                assert run_every and run_every > 0
+                def deco(fn):
+                    def run_by_timer():
+                        for k in range(5):                        # Streamlit's timer: the fragment alone re-runs, again and again
+                            if k == 3:
+                                self.aoa = 11.5                   # the user moves the slider between two runs
+                            fn()
+                            self.timer_runs += 1
+                    return run_by_timer
+                return deco
+
+        st2 = New(st.session_state)
+        again = build_lbm_component(coords, "NACA 2412", nx=256, ny=128, frames_per_update=1, st=st2)
+        assert again is wt and st2.timer_runs == 5 and wt.aoa_deg == 11.5
+        assert len([c for c in st2.calls if c[0] == "image"]) == 5 and wt.steps == 7 * 2 * 4 + 5 * 4
+    finally:
+        wt.close()
+
+
 def test_composited_png_of_a_running_tunnel(pkg, tmp_path):
     """f2 end to end: field from the GPU colour-map kernel, tracer strokes from the GPU advection, compositor on the
     host, PNG under the page's file name (html:980-1000)."""
