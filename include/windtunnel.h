@@ -82,25 +82,30 @@ int wt_get_info(const wt_handle *h, wt_info *info);
 const char *wt_last_error(void);
 const char *wt_version(void);
 
-/* Tuning knobs (no counterpart in the reference).
- *   "fuse_steps" (0 / 1 = where it pays / 2 = always): advance SEVERAL steps per pass over the lattice — marching kernels
- *       that keep the intermediate steps in registers, body / inlet / outlet included (csrc/step_march.hpp: two steps,
- *       csrc/step_march3.hpp: three); results are bit-identical either way.  fp32 and fp64 handles (whole lattices and slabs) with an even NY, at least 8 local
- *       columns and a lattice below 4 GiB.  Default: 1 (environment WT_FUSE2=0|1|2 overrides at wt_create); handles
- *       that are not eligible, or too small for it to pay, stay on the single-step kernel.
- *   "fuse_depth" (0 = automatic / 2 / 3 / 4): steps per pass.  Default 3 where it pays, 4 on lattices with long units (fp32: 2
- *       sites per lane, fp64: 1; needs 16 local columns).  A step count that is not a multiple is finished with shorter passes
- *       or single steps.
- *   "fuse_sites" (0 = automatic / 2 / 4): sites per lane of the two-step marching kernel = window height / 64.  fp64 handles
- *       use 2; fp32 handles 4 (256-row windows) on wide lattices and 2 (128-row windows, twice the units) on narrow
- *       ones such as column slabs; 4 needs NY % 4 == 0.
- *   "fuse_chunk": cost limit of one marching unit in columns (0 = whole resident rounds of units, the default).
- *   "fast_div" (default 1): divide by tau through a reciprocal and two fused multiply-adds where an exhaustive
- *       on-device check over all 2^23 significands has PROVED the sequence equal to the IEEE quotient for this tau
- *       (csrc/d2q9.hpp); 0 keeps the IEEE division everywhere.  Bit-identical either way.
- *       fp32 only (fp64 always divides in IEEE arithmetic).
- * wt_get_option also reports "fuse_active", "fuse_units", "fuse_depth" / "fuse_sites" (in use), "fuse_tiles_general",
- * "fast_div_active". */
+/* Tuning knobs (no counterpart in the reference).  Every setting but "fast_math" gives bit-identical results.
+ *   "fuse_steps" (0 / 1 = where it pays / 2 = always): advance SEVERAL steps per pass over the lattice — marching kernels that keep
+ *       the intermediate steps in registers, body / inlet / outlet included (csrc/step_march.hpp: two steps, csrc/step_march3.hpp:
+ *       three and four, csrc/step_chain.hpp: the same with workgroups whose units share their edge columns).  fp32 (even NY) and
+ *       fp64 handles, whole lattices and slabs, with at least 8 local columns and a lattice below 4 GiB.  Default 1 (environment
+ *       WT_FUSE2=0|1|2 overrides at wt_create); handles that are not eligible, or too small for it to pay, stay on k_step.
+ *   "fuse_depth" (0 = automatic / 2 / 3 / 4): steps per pass.  Automatic: 4 from eight columns per resident unit up (fp64: 24;
+ *       3 below), 2 on narrower fp32 lattices.  A step count that is not a multiple is finished with SHORTER FUSED passes on the
+ *       same tables (5 = 3 + 2, 4 = 2 + 2 — a remainder of one step is never left behind where two passes fit); single steps only
+ *       where not even two exact ghost columns / steps are left.  An fp32 tau for which the fast division is not proved takes
+ *       three-step passes on a four-step plan (the IEEE four-step kernel is not built).
+ *   "chain" (default 1): plain-fluid workgroups march their four units in alternating directions and hand the edge columns over
+ *       through LDS instead of recomputing them (csrc/step_chain.hpp).
+ *   "fuse_chunk": cost limit of one marching unit in columns (0 = the default: units cut by TIME into one resident round).
+ *   "fuse_sites": kept for callers of round 2; the sites per lane are fixed by the element type (fp32 2, fp64 1).
+ *   "fast_div" (default 1): divide by tau through a reciprocal and two fused multiply-adds where an exhaustive on-device check over
+ *       all 2^23 significands has PROVED the sequence equal to the IEEE quotient for this tau (csrc/d2q9.hpp); 0 keeps the IEEE
+ *       division everywhere.  fp32 only (fp64 always divides in IEEE arithmetic).
+ *   "fast_math" (default 0, fp32, OPT-IN, NOT bit-identical): the marching kernels collide with contracted arithmetic — fused
+ *       multiply-adds, v_rcp / v_rsq for the divisions and the square root (csrc/d2q9.hpp collide_contracted).  Held to BASELINE.md's
+ *       tolerance against the oracle (|d rho| <= 1e-5, |d u| <= 5e-6; tests/test_gpu_fast_math.py), +19 % on 4096^2, +36 % on a
+ *       544-column slab.  k_step (single steps, HBM-bound) keeps the reference arithmetic.
+ * wt_get_option also reports "fuse_active", "fuse_units", "chain_units", "fuse_depth" / "fuse_sites" (in use), "fuse_tiles_general",
+ * "fast_div_active", "passes" and "single_steps" (fused passes / whole k_step steps since the last init or wt_write_f). */
 int wt_set_option(wt_handle *h, const char *name, double value);
 int wt_get_option(const wt_handle *h, const char *name, double *value);
 
