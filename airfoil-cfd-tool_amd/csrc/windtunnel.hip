@@ -499,20 +499,24 @@ static int rebuild_fuse_plan(wt_handle *h)
     const long slots = (long)prop.multiProcessorCount * 4 * waves;
     const int s3 = h->dtype == WT_F32 ? 2 : 1;
     const bool two_on_three = h->dtype != WT_F32 && h->fuse_depth == 2;  // fp64: two-step passes on the three-step tables
-    const bool depth3_ok = h->g.nxl >= 16 && (h->fuse_depth != 2 || two_on_three);
+    // Every slab of a tunnel must take the SAME sequence of passes and refresh steps (the exchange is collective: over RCCL each rank
+    // decides on its own), so the automatic choices below look at the NARROWEST slab of the split — an edge slab, W + halo columns —
+    // whatever this slab's own width is: a quantity every rank computes alike from (nx_global, nranks, halo).
+    const int plan_nxl = h->nranks > 1 ? h->nx_g / h->nranks + h->halo : h->g.nxl;
+    const bool depth3_ok = std::min(h->g.nxl, plan_nxl) >= 16 && (h->fuse_depth != 2 || two_on_three);
     if (depth3_ok) {
         // Steps per pass (round 3, tools/run_width_sweep.sh, us per step on 4096 rows, fp32, steps per pass 2 / 3 / 4): 288 columns 16.5 / 17.7 /
         // 18.9; 416: 20.9 / 21.3 / 22.1; 544: 25.0 / 24.7 / 24.4; 800: 33.5 / 30.1 / 28.3; 1056: 41.4 / 36.8 / 33.5; 2080: - / 65.1 / 59.8; 4096: - /
         // 114.3 / 96.7 — four steps per pass from eight columns per resident unit up, two below (the two-step kernel further down);
         // fp64 (round 2): 4096^2 82.4 -> 87.9 GLUPS with four, 4096 x 2048 72.5 -> 75.5, 1056 columns +1 %, three below 24 columns per unit.
-        const long tiles3 = (long)(h->g.nxl - 4) * march_nwin(h->g.ny, 64 * s3);
+        const long tiles3 = (long)(plan_nxl - 4) * march_nwin(h->g.ny, 64 * s3);
         const bool f32 = h->dtype == WT_F32;
         if (f32 && h->fuse_depth == 0 && !h->fuse_force && h->fuse_chunk <= 0 && tiles3 / slots < 8) goto two_step;
         const int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (f32 ? 8 : 24)) ? 4 : 3;
         const MarchRange r = march_range3(h->g, depth);
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
         const bool force = h->fuse_force || h->fuse_depth >= 2;
-        if (force || h->fuse_chunk > 0 || tiles / slots >= 6) {
+        if (force || h->fuse_chunk > 0 || tiles3 / slots >= 6) {
             // ONE resident round of units with chain blocks (their units can be as long as the lattice asks for; tools/r3_rounds.sh: 2080 columns 52.9
             // against 55.8 us per step with two rounds of half the length, 3000^2 56.7 / 60.5, 4096^2 90.4 / 92.9); without them two rounds
             // where that leaves at least 12 columns per unit, as in round 2
@@ -531,7 +535,8 @@ two_step:
     if (h->fuse_depth >= 3 || h->dtype != WT_F32) return WT_OK;
     // fp32, two steps per pass on 128-row windows (measured with 4096 rows: 288 columns = 4.5 per unit 16.6 us/step against 20.9 for
     // single steps and 18.5 for three steps per pass)
-    const long target = march_target_units(h, 2, slots, h->fuse_force, 4);
+    if (!h->fuse_force && h->fuse_chunk <= 0 && (long)(plan_nxl - 2) * march_nwin(h->g.ny, 128) / slots < 4) return WT_OK;     // (the narrowest slab decides)
+    const long target = march_target_units(h, 2, slots, true, 4);
     if (target == 0) return WT_OK;
     WT_TRY(build_fuse_plan(h, 2, target, 2));
     h->fuse_ready = h->n_units > 0;
@@ -1023,7 +1028,10 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     h->steps_done += depth;
     h->passes += 1;
     h->seams_valid = true;
-    if (h->nranks > 1) h->ghost_valid -= depth;  // one column of ghost validity consumed per step
+    // One column of ghost validity is consumed per step — and the units of a depth-D plan leave the D-1 columns next to a local edge
+    // unwritten whatever the pass advances (march_range3), so a SHORTER pass on those tables still costs D-1 columns of the fresh ghosts
+    // (found by the mixed-depth group test: two-step passes on four-step tables right after an initialisation).
+    if (h->nranks > 1) h->ghost_valid = std::min(h->ghost_valid - depth, h->halo - (h->march_depth - 1));
     return WT_OK;
 }
 
@@ -1220,8 +1228,7 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
     for (int r = 0; r < n; r++) {
         WT_TRY(check_steppable(hs[r], nsteps, tau, u0));
         if (n > 1 && hs[r]->transport != TR_LOCAL) return fail(WT_ERR_STATE, "handle %d is not locally linked", r);
-        if (hs[r]->ghost_valid != hs[0]->ghost_valid || hs[r]->steps_done != hs[0]->steps_done)
-            return fail(WT_ERR_STATE, "slabs are not at the same step");
+        if (hs[r]->steps_done != hs[0]->steps_done) return fail(WT_ERR_STATE, "slabs are not at the same step");
     }
     for (int r = 0; r < n; r++) {
         HIP_TRY(hipSetDevice(hs[r]->device));
@@ -1249,7 +1256,8 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
             continue;
         }
         const bool emit = (s == nsteps - 1);
-        const bool refresh = n > 1 && hs[0]->ghost_valid == 0;
+        bool refresh = false;                             // as soon as ANY slab has no exact ghost column left, all of them refresh
+        for (int r = 0; r < n && n > 1; r++) refresh = refresh || hs[r]->ghost_valid <= 0;
         if (refresh) {
             // every slab's comm stream must see its neighbours' finished lattices ...
             for (int r = 0; r < n; r++) {

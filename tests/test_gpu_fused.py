@@ -311,3 +311,40 @@ def test_remainder_of_one_never_falls_back_to_single_steps(pkg, oracle_c):
             e.step(n, 0.58, 0.06)
         assert e.get_option("single_steps") == 0 and e.info().steps_done == 27
         assert bits_equal(e.read_f(), fr)
+
+
+def test_slabs_choose_one_plan_depth_and_mixed_groups_still_take_fused_passes(pkg):
+    """Every slab of a tunnel must take the same sequence of passes and refresh steps (over RCCL each rank decides alone, and the exchange is
+    collective), so the automatic steps per pass come from the NARROWEST slab of the split: here an edge slab (W + halo = 512 columns, 7.9 per
+    resident unit -> two steps per pass) decides for the interior slabs too (528 columns: alone they would plan four).  And when the depths DO
+    differ (forced per handle — ADVICE r2), wt_step_group runs passes of the length every slab can take and refreshes as soon as any slab has
+    run out of exact ghost columns: a two-step pass on four-step tables still costs the three unwritten columns next to a local edge."""
+    nranks, halo, nx, ny = 4, 16, 4 * 496, 4096
+    mask = _body(pkg, nx, ny, "naca2412", 7.0)
+    steps = [17, 16]
+    with pkg.Engine(nx, ny) as ref:
+        ref.set_option("fuse_steps", 0)
+        ref.set_mask(mask); ref.init_equilibrium(0.06)
+        for n in steps:
+            ref.step(n, 0.58, 0.06)
+        f0 = ref.read_f()
+    for forced in (False, True):
+        es = [pkg.Engine(nx, ny, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+        try:
+            pkg.Engine.link_local(es)
+            for r, e in enumerate(es):
+                if forced and 0 < r < nranks - 1:
+                    e.set_option("fuse_depth", 4)
+                e.set_mask(mask); e.init_equilibrium(0.06)
+            depths = [int(e.get_option("fuse_depth")) for e in es]
+            assert all(e.get_option("fuse_active") == 1.0 for e in es)
+            assert depths == ([2, 4, 4, 2] if forced else [2, 2, 2, 2]), depths
+            for n in steps:
+                pkg.Engine.step_group(es, n, 0.58, 0.06)
+            # 33 steps with a few ghost refreshes: everything else went through fused passes on every slab
+            assert all(e.get_option("passes") >= 12 and e.get_option("single_steps") <= 6 for e in es), [(e.get_option("passes"), e.get_option("single_steps")) for e in es]
+            f1 = np.concatenate([e.read_f() for e in es], axis=2)
+        finally:
+            for e in es:
+                e.close()
+        assert bits_equal(f0, f1), forced
