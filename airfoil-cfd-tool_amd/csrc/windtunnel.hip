@@ -508,11 +508,11 @@ static int rebuild_fuse_plan(wt_handle *h)
         // Steps per pass (round 3, tools/run_width_sweep.sh, us per step on 4096 rows, fp32, steps per pass 2 / 3 / 4): 288 columns 16.5 / 17.7 /
         // 18.9; 416: 20.9 / 21.3 / 22.1; 544: 25.0 / 24.7 / 24.4; 800: 33.5 / 30.1 / 28.3; 1056: 41.4 / 36.8 / 33.5; 2080: - / 65.1 / 59.8; 4096: - /
         // 114.3 / 96.7 — four steps per pass from eight columns per resident unit up, two below (the two-step kernel further down);
-        // fp64 (round 2): 4096^2 82.4 -> 87.9 GLUPS with four, 4096 x 2048 72.5 -> 75.5, 1056 columns +1 %, three below 24 columns per unit.
+        // fp64 (tools/r3_f64_sweep.sh, three / four steps per pass): 288 columns 24.5 / 24.2, 544: 36.9 / 36.4, 1056: 63.8 / 60.0, 2080: 115.9 / 107.6, 4096: 236.6 / 212.3 - four from 12 columns per unit up.
         const long tiles3 = (long)(plan_nxl - 4) * march_nwin(h->g.ny, 64 * s3);
         const bool f32 = h->dtype == WT_F32;
         if (f32 && h->fuse_depth == 0 && !h->fuse_force && h->fuse_chunk <= 0 && tiles3 / slots < 8) goto two_step;
-        const int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (f32 ? 8 : 24)) ? 4 : 3;
+        const int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (f32 ? 8 : 12)) ? 4 : 3;
         const MarchRange r = march_range3(h->g, depth);
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
         const bool force = h->fuse_force || h->fuse_depth >= 2;

@@ -88,7 +88,7 @@ const char *wt_version(void);
  *       three and four, csrc/step_chain.hpp: the same with workgroups whose units share their edge columns).  fp32 (even NY) and
  *       fp64 handles, whole lattices and slabs, with at least 8 local columns and a lattice below 4 GiB.  Default 1 (environment
  *       WT_FUSE2=0|1|2 overrides at wt_create); handles that are not eligible, or too small for it to pay, stay on k_step.
- *   "fuse_depth" (0 = automatic / 2 / 3 / 4): steps per pass.  Automatic: 4 from eight columns per resident unit up (fp64: 24;
+ *   "fuse_depth" (0 = automatic / 2 / 3 / 4): steps per pass.  Automatic: 4 from eight columns per resident unit up (fp64: 12;
  *       3 below), 2 on narrower fp32 lattices.  A step count that is not a multiple is finished with SHORTER FUSED passes on the
  *       same tables (5 = 3 + 2, 4 = 2 + 2 — a remainder of one step is never left behind where two passes fit); single steps only
  *       where not even two exact ghost columns / steps are left.  An fp32 tau for which the fast division is not proved takes
