@@ -276,8 +276,6 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     const bool far_win = (w == 0) || (row0 + M3_WIN >= g.ny);
     March3Addr<T, S> m;
     MarchAddr<T, S> &a = m.a;
-    m.young = (blockIdx.x * 2 >= gridDim.x) ? 1 : 0;
-    if (p.prio == 2) march_prio(m.young);
     a.rs = march_rsrc(p.fs, p.lat_bytes);
     a.rd = march_rsrc(p.fd, p.lat_bytes);
     a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * EB));

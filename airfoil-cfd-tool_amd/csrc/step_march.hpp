@@ -299,7 +299,6 @@ struct MarchParams {
     T tau;
     T U0;
     int rev;
-    int prio;                  // experiment (WT_PRIO): 1 = the two waves of a SIMD take turns at issue priority, iteration by iteration; 2 = the later-dispatched half of the grid has priority
 };
 
 // S consecutive rows of one column and direction, held by one lane

@@ -313,16 +313,8 @@ __device__ unsigned long long g_m3_stamps[8];
 #define M3_STAMP(i) do { } while (0)
 #endif
 
-// issue priority of this wave among the waves of its SIMD (s_setprio takes an immediate)
-__device__ __forceinline__ void march_prio(int hi)
-{
-    if (hi) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(0);
-}
-
 template <typename T, int S>
 struct March3Addr {
-    int young;                           // this workgroup belongs to the later-dispatched half of the grid (the second wave of its SIMD)
     MarchAddr<T, S> a;                   // lattice / macro descriptors and offsets (its seam fields are unused here)
     __amdgpu_buffer_rsrc_t rs3;          // seam buffer S3
     unsigned voff_lo, voff_hi;           // lanes 0 .. 10 sizeof(T)/4 - 1: byte offsets of their 16-byte chunk in the two half records this window writes
@@ -499,7 +491,6 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     // stores makes hipcc's waitcnt pass drain vmcnt(0) at the merge points of every iteration.
 #pragma unroll 1
     for (int x = ia; x <= xend; x++) {
-        if (p.prio == 1) march_prio((x ^ m.young) & 1);
         V3 nxt[9];
         march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);               // prefetch (last one: harmless re-load)
         const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
@@ -636,7 +627,6 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     int seam_col = -1;
 #pragma unroll 1
     for (int x = xs; x <= xend; x++) {
-        if (p.prio == 1) march_prio((x ^ m.young) & 1);
         V3 nxt[9];
         march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has3 = x - 3 >= ia;                                         // column x-3 is an output column

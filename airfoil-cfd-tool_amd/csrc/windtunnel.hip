@@ -933,7 +933,6 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)((h->steps_done >> 1) & 1);
-    p.prio = 0;
     {
         static const int rev_mode = getenv("WT_MARCH_REV") ? atoi(getenv("WT_MARCH_REV")) : 2;     // experiments: 0 / 1 = fixed order
         if (rev_mode == 0 || rev_mode == 1) p.rev = rev_mode;
@@ -990,10 +989,6 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)(h->passes & 1);
-    {
-        static const int prio_mode = getenv("WT_PRIO") ? atoi(getenv("WT_PRIO")) : 0;
-        p.prio = prio_mode;
-    }
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
         if (h->march_depth == 4) {      // the plan's tables are those of the four-step pass, whatever this pass advances
