@@ -9,19 +9,19 @@
 //               start seam        end seam        start seam
 //
 // so that both units of a pair begin at their common seam, and the inner units B0 and A1 finish at theirs.  At a start seam each
-// unit publishes, level by level, the three populations of its first column that move across the seam (LDS, one workgroup barrier
-// per level) and takes its partner's in place of the "column behind" it would otherwise have recomputed; at an end seam the same
+// unit publishes, level by level, the three populations of its first column that move across the seam (LDS: data, then a flag the
+// partner polls) and takes its partner's in place of the "column behind" it would otherwise have recomputed; at an end seam the same
 // happens with the last column and the "column ahead".  No site is computed twice inside the block; only its two outer ends
 // (A0's left, B1's right) still overlap with the neighbouring blocks.  Stage executions per unit: 3 L + 1.5 on average instead of
 // 3 L + 8 (T = 3), 4 L + 3 instead of 4 L + 18 (T = 4).
 //
-// The fill and drain iterations are PEELED (an iteration template with a compile-time stage mask) rather than run on don't-care
-// values, and the barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier): the prefetched column and the stores of the
-// previous iteration stay in flight across them.
+// The fill and drain iterations are PEELED (an iteration template with a compile-time stage mask and hand-over hooks) rather than
+// run on don't-care values; there is ONE workgroup barrier, behind the clearing of the flags at the start of the kernel.
 //
 // Chain blocks are plain interior fluid throughout (the planner checks the window-tile classes of the block's whole footprint and
-// keeps it away from the inlet / outlet columns; every unit holds at least depth + 1 columns): no mask, no bounce codes, no class tests.  Everything else — body, inlet,
-// outlet, short units, two-step passes — stays with the solo units of step_march3.hpp, in the same launch.
+// keeps it away from the inlet / outlet columns; every unit holds at least depth + 1 columns): no mask, no bounce codes, no class
+// tests.  Everything else — body, inlet, outlet, short units, two-step passes — stays with the solo units of step_march3.hpp, in the
+// same launch.  Units are cut by time and placed by build_chain_plan_timed (bottom of this file).
 // Every site still goes through the arithmetic of k_step once per level: bit-identical results.
 #pragma once
 #include "step_march3.hpp"
