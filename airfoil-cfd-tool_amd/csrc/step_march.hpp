@@ -144,15 +144,6 @@ __global__ __launch_bounds__(256) void k_seam_flags(const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // One lattice site, step 1 only, every branch of STEP_FS main() (html:283-360) in the reference's order —
 // the arithmetic of site_general (kernels.hpp) with the relaxation of collide_t.
-// A select between two elements of a private array (`side ? o[4] : o[2]`) is turned by hipcc into ONE load at a computed index, which keeps
-// the whole array in scratch memory; values that passed through an empty asm are plain registers, and the select becomes a v_cndmask.
-template <typename T> __device__ __forceinline__ T in_register(T x)
-{
-    asm volatile("" : "+v"(x));
-    return x;
-}
-template <typename T> __device__ __forceinline__ T pick(bool second, T a, T b) { return second ? in_register(b) : in_register(a); }
-
 template <typename T, int FD>
 __device__ __forceinline__ void site_step1(const T *__restrict__ s, const uint8_t *__restrict__ m, const Geom &g, int i, int j,
                                            const FastDiv &fdv, T tau, T U0, T (&out)[9])
@@ -161,10 +152,10 @@ __device__ __forceinline__ void site_step1(const T *__restrict__ s, const uint8_
     const int gi = i + g.gi0;
     if (m[c]) {                                                    // html:287-294 solid
 #pragma unroll
-        for (int k = 0; k < 9; k++) out[k] = in_register(s[opp_of(k) * g.plane + c]);
+        for (int k = 0; k < 9; k++) out[k] = s[opp_of(k) * g.plane + c];
     } else if (gi == g.nx_g - 1) {                                 // html:301-312 outlet
 #pragma unroll
-        for (int k = 0; k < 9; k++) out[k] = in_register(s[k * g.plane + c - g.pitch]);
+        for (int k = 0; k < 9; k++) out[k] = s[k * g.plane + c - g.pitch];
     } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
         feq_all<T>(T(1), U0, T(0), out);
     } else {                                                       // html:324-359 interior fluid
@@ -269,7 +260,7 @@ __global__ __launch_bounds__(256) void k_halo_from_seams(const T *__restrict__ f
     }
     typedef T t4 __attribute__((ext_vector_type(4)));
     t4 *out = reinterpret_cast<t4 *>(halo + ((long)b * (g.nxl + 2) + x + 1) * 8);
-    out[side] = t4{pick(side != 0, o[2], o[4]), pick(side != 0, o[5], o[7]), pick(side != 0, o[6], o[8]), T(0)};
+    out[side] = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
 }
 
 // ------------------------------------------------------------------------------------------------

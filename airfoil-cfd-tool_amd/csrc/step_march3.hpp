@@ -78,11 +78,9 @@ __global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T
         const int cl = threadIdx.x >> 2, r4 = threadIdx.x & 3;
         const int x = x0 - 1 + cl;
         const int j = M3_WIN * b - 2 + r4;
-        // (every path stores its own nine values: merging the paths' result arrays first makes hipcc keep part of them in scratch memory)
-        auto put = [&](const T (&v)[9]) {
+        T o[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) l1[cl][r4][k] = v[k];
-        };
+        for (int k = 0; k < 9; k++) o[k] = T(0);
         if (x >= 0 && x < g.nxl && j < g.ny) {
             // the nine seam-buffer inputs are requested together with the flag (not behind it): this kernel is a chain of memory
             // latencies, and the records of columns x-1 .. x+1 exist for every x (pad records at both ends)
@@ -95,20 +93,14 @@ __global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T
             }
             const bool plain = use_seams && ((flags3[(long)(b - 1) * g.nxl + x] >> r4) & 1) != 0;
             if (plain) {
-                T o[9], rho, ux, uy;
+                T rho, ux, uy;
                 collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
-                put(o);
             } else {
-                T o[9];
                 site_step1<T, FD>(fs + g.pitch, m, g, x, j, fdv, tau, U0, o);
-                put(o);
             }
-        } else {
-            T o[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) o[k] = T(0);
-            put(o);
         }
+#pragma unroll
+        for (int k = 0; k < 9; k++) l1[cl][r4][k] = o[k];
     }
     __syncthreads();
     {   // ---- phase 2
@@ -151,7 +143,7 @@ __global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T
         const long rec = ((long)b * (g.nxl + 2) + x + 1) * 8 + side * 4;
         typedef T t4 __attribute__((ext_vector_type(4)));
         const t4 v1 = side ? t4{get(4, 0, 0), get(7, 0, 0), get(8, 0, 0), T(0)} : t4{get(2, 0, 0), get(5, 0, 0), get(6, 0, 0), T(0)};
-        const t4 v2 = t4{pick(side != 0, o[2], o[4]), pick(side != 0, o[5], o[7]), pick(side != 0, o[6], o[8]), T(0)};
+        const t4 v2 = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
         *reinterpret_cast<t4 *>(h1 + rec) = v1;
         *reinterpret_cast<t4 *>(h2 + rec) = v2;
     }
@@ -240,10 +232,9 @@ __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T
         const int cl = w / 6, r6 = w % 6;
         const int x = x0 - 2 + cl;
         const int j = WIN * b - 3 + r6;
-        auto put = [&](const T (&v)[9]) {
+        T o[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) l1[cl][r6][k] = v[k];
-        };
+        for (int k = 0; k < 9; k++) o[k] = T(0);
         if (x >= 0 && x < g.nxl && j < g.ny) {
             T a[9];
             const T *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
@@ -254,20 +245,14 @@ __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T
             }
             const bool plain = use_seams && ((flags4[(long)(b - 1) * g.nxl + x] >> r6) & 1) != 0;
             if (plain) {
-                T o[9], rho, ux, uy;
+                T rho, ux, uy;
                 collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
-                put(o);
             } else {
-                T o[9];
                 site_step1<T, FD>(fs + g.pitch, m, g, x, j, fdv, tau, U0, o);
-                put(o);
             }
-        } else {
-            T o[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) o[k] = T(0);
-            put(o);
         }
+#pragma unroll
+        for (int k = 0; k < 9; k++) l1[cl][r6][k] = o[k];
     }
     __syncthreads();
     // ---- level 2: columns cl = 1..62, rows WIN b - 2 + r4
@@ -298,7 +283,7 @@ __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T
         const T *p1 = l1[cl][2 + side], *p2 = l2[cl][1 + side];
         *reinterpret_cast<t4 *>(h1 + rec) = side ? t4{p1[4], p1[7], p1[8], T(0)} : t4{p1[2], p1[5], p1[6], T(0)};
         *reinterpret_cast<t4 *>(h2 + rec) = side ? t4{p2[4], p2[7], p2[8], T(0)} : t4{p2[2], p2[5], p2[6], T(0)};
-        *reinterpret_cast<t4 *>(h3 + rec) = t4{pick(side != 0, o[2], o[4]), pick(side != 0, o[5], o[7]), pick(side != 0, o[6], o[8]), T(0)};
+        *reinterpret_cast<t4 *>(h3 + rec) = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
     }
 }
 
