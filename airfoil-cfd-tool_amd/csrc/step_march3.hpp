@@ -214,6 +214,12 @@ __device__ __forceinline__ void halo_step(const uint8_t *__restrict__ m, const G
 // lattice, level 2 of rows WIN b - 2 .. WIN b + 1 x 62 columns, level 3 of rows WIN b - 1, WIN b x 60 columns, in LDS; H1, H2, H3
 // take the two rows next to the seam of each level (layout as in k_halo3).
 static constexpr int H4_COLS = 60;
+#ifdef WT_UNIT_CLOCKS
+__device__ unsigned long long g_halo_clk[8];      // diagnostic build: clocks of k_halo4's phases, summed over workgroups (+ count)
+#define H4_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_halo_clk[i], t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define H4_STAMP(i) do { } while (0)
+#endif
 template <typename T, int S, int FD>
 __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
                                                const uint8_t *__restrict__ flags4, T *__restrict__ h1, T *__restrict__ h2, T *__restrict__ h3, Geom g,
@@ -227,6 +233,9 @@ __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T
     const int x0 = (int)(blockIdx.x % nblk_x) * H4_COLS;          // first output column; l1 / l2 column index cl <-> x0 - 2 + cl
     const uint8_t *m = mask + g.pitch;
     typedef T t4 __attribute__((ext_vector_type(4)));
+#ifdef WT_UNIT_CLOCKS
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
     // ---- level 1: 64 columns x 6 rows
     for (int w = threadIdx.x; w < 64 * 6; w += 256) {
         const int cl = w / 6, r6 = w % 6;
@@ -254,7 +263,9 @@ __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T
 #pragma unroll
         for (int k = 0; k < 9; k++) l1[cl][r6][k] = o[k];
     }
+    H4_STAMP(0);
     __syncthreads();
+    H4_STAMP(1);
     // ---- level 2: columns cl = 1..62, rows WIN b - 2 + r4
     if (threadIdx.x < 62 * 4) {
         const int cl = 1 + threadIdx.x / 4, r4 = threadIdx.x % 4;
@@ -268,7 +279,9 @@ __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T
 #pragma unroll
         for (int k = 0; k < 9; k++) l2[cl][r4][k] = o[k];
     }
+    H4_STAMP(2);
     __syncthreads();
+    H4_STAMP(3);
     // ---- level 3 and the three tables: columns cl = 2..61, side 0 = row WIN b - 1, side 1 = row WIN b
     if (threadIdx.x < H4_COLS * 2) {
         const int cl = 2 + threadIdx.x / 2, side = threadIdx.x & 1;
@@ -285,6 +298,10 @@ __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T
         *reinterpret_cast<t4 *>(h2 + rec) = side ? t4{p2[4], p2[7], p2[8], T(0)} : t4{p2[2], p2[5], p2[6], T(0)};
         *reinterpret_cast<t4 *>(h3 + rec) = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
     }
+    H4_STAMP(4);
+#ifdef WT_UNIT_CLOCKS
+    if (threadIdx.x == 0) atomicAdd(&g_halo_clk[7], 1ULL);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

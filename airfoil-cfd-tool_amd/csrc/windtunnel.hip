@@ -554,6 +554,13 @@ extern "C" int wt_debug_m3_stamps(unsigned long long *out, int reset)
 #endif
 
 #ifdef WT_UNIT_CLOCKS         // diagnostic build only (tools/unit_clocks.py); not part of the ABI
+extern "C" int wt_debug_halo_clocks(unsigned long long *out, int reset)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(wt::g_halo_clk), 8 * sizeof(unsigned long long)));
+    if (reset) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(wt::g_halo_clk), z, sizeof(z))); }
+    return WT_OK;
+}
 extern "C" int wt_debug_unit_clocks(wt_handle *h, unsigned long long *clk, int *units4, int cap)
 {
     WT_TRY(check_handle(h));
