@@ -512,7 +512,11 @@ static int rebuild_fuse_plan(wt_handle *h)
         const long tiles3 = (long)(plan_nxl - 4) * march_nwin(h->g.ny, 64 * s3);
         const bool f32 = h->dtype == WT_F32;
         if (f32 && h->fuse_depth == 0 && !h->fuse_force && h->fuse_chunk <= 0 && tiles3 / slots < 8) goto two_step;
-        const int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (f32 ? 8 : 12)) ? 4 : 3;
+        int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (f32 ? 8 : 12)) ? 4 : 3;
+        // The units of a depth-D plan leave the D-1 columns next to a local slab edge unwritten: those must all be GHOST columns, so a slab
+        // with fewer than D-1 of them plans shallower (halo 2: three steps per pass at most; halo 1: the two-step kernel, whose units leave one).
+        if (h->nranks > 1 && h->halo < depth - 1) depth = h->halo + 1;
+        if (depth < 3) { if (f32) goto two_step; return WT_OK; }
         const MarchRange r = march_range3(h->g, depth);
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
         const bool force = h->fuse_force || h->fuse_depth >= 2;
@@ -854,7 +858,7 @@ static int halo_begin(wt_handle *h)
     return WT_OK;
 }
 
-static inline bool needs_halo(const wt_handle *h) { return h->nranks > 1 && h->ghost_valid == 0; }
+static inline bool needs_halo(const wt_handle *h) { return h->nranks > 1 && h->ghost_valid <= 0; }
 
 // One step of one handle.  `refreshed`: halo_begin was enqueued for this step; the refresh is
 // overlapped with the interior columns:  [ghost refresh on s_comm] || [interior on s_compute]
@@ -1033,7 +1037,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     // One column of ghost validity is consumed per step — and the units of a depth-D plan leave the D-1 columns next to a local edge
     // unwritten whatever the pass advances (march_range3), so a SHORTER pass on those tables still costs D-1 columns of the fresh ghosts
     // (found by the mixed-depth group test: two-step passes on four-step tables right after an initialisation).
-    if (h->nranks > 1) h->ghost_valid = std::min(h->ghost_valid - depth, h->halo - (h->march_depth - 1));
+    if (h->nranks > 1) h->ghost_valid = std::max(0, std::min(h->ghost_valid - depth, h->halo - (h->march_depth - 1)));
     return WT_OK;
 }
 

@@ -219,6 +219,8 @@ def test_long_run_fused_equals_single_step_and_stays_finite(pkg):
     (4, 17, 2048, 512, [33, 18], "float32", 2, 3),
     (2, 2, 512, 256, [9], "float32", 2, 3),              # halo 2: never three exact ghost columns -> single steps only
     (8, 16, 4096, 256, [50], "float32", 0, 0),           # automatic choice
+    (2, 2, 2304, 4096, [9, 6], "float32", 0, 0),         # wide slabs would plan four steps per pass, but two ghost columns allow three at most
+    (2, 1, 2304, 4096, [5], "float32", 0, 0),            # one ghost column: the two-step kernel's tables (its units leave one column), no fused pass fits
 ])
 def test_fused_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, chunks, dtype, sites, depth):
     """Two-steps-per-launch on column slabs (in-process transport): a pair needs two exact ghost
