@@ -24,7 +24,7 @@ EXPORTS = (
     "wt_create", "wt_create_slab", "wt_destroy", "wt_get_info", "wt_last_error", "wt_version",
     "wt_set_option", "wt_get_option",
     "wt_comm_unique_id", "wt_comm_init_rank", "wt_comm_selftest", "wt_link_local", "wt_step_group", "wt_step_group_timed",
-    "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_read_f", "wt_write_f",
+    "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_plan_steps", "wt_read_f", "wt_write_f",
     "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_clamp_events", "wt_field", "wt_render_rgba", "wt_advect_tracers", "wt_sync",
 )
 
@@ -83,6 +83,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "wt_init_equilibrium": ([H, c_double], c_int),
         "wt_step": ([H, c_int, c_double, c_double], c_int),
         "wt_step_timed": ([H, c_int, c_double, c_double, POINTER(c_float)], c_int),
+        "wt_plan_steps": ([H, c_int, c_double, POINTER(c_int), c_int], c_int),
         "wt_read_f": ([H, c_void_p], c_int),
         "wt_write_f": ([H, c_void_p], c_int),
         "wt_read_macro": ([H, c_void_p, c_void_p, c_void_p], c_int),
@@ -211,6 +212,15 @@ class Engine:
 
     def step(self, nsteps: int, tau: float, u0: float) -> None:
         _check(self._lib.wt_step(self._h, int(nsteps), float(tau), float(u0)))
+
+    def plan_steps(self, nsteps: int, tau: float):
+        """The sequence of passes / single steps / refresh steps `step(nsteps)` would take now (+k, 1, -1), without taking them."""
+        cap = int(nsteps) + 1
+        seq = (c_int * cap)()
+        n = self._lib.wt_plan_steps(self._h, int(nsteps), float(tau), seq, cap)
+        if n < 0:
+            _check(n)
+        return [int(v) for v in seq[:n]]
 
     def step_timed(self, nsteps: int, tau: float, u0: float) -> float:
         ms = c_float()

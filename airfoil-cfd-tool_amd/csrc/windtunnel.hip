@@ -1104,6 +1104,37 @@ static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
     return WT_OK;
 }
 
+// How would `nsteps` steps be taken from the handle's present state?  The decisions of run_steps without a launch: +k = one fused pass of k
+// steps, 1 = a single step, -1 = a single step that refreshes the ghost columns first.  Every slab of a tunnel must produce the SAME sequence
+// (over RCCL each rank decides alone and the exchange is collective): tests/test_gpu_slabs.py compares the ranks' answers.
+extern "C" int wt_plan_steps(wt_handle *h, int nsteps, double tau, int *seq, int cap)
+{
+    WT_TRY(check_handle(h));
+    if (nsteps < 0 || !seq || cap < 0) return fail(WT_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    WT_TRY(set_tau_cap(h, tau));
+    const int gv0 = h->ghost_valid;
+    int n = 0, s = 0;
+    while (s < nsteps) {
+        const int k = fuse_stride(h, nsteps - s);
+        int code;
+        if (k > 0) {
+            code = k;
+            if (h->nranks > 1) h->ghost_valid = std::max(0, std::min(h->ghost_valid - k, h->march_depth >= 3 ? h->halo - (h->march_depth - 1) : h->ghost_valid - k));
+            s += k;
+        } else {
+            const bool refresh = needs_halo(h);
+            code = refresh ? -1 : 1;
+            if (h->nranks > 1) h->ghost_valid = refresh ? h->halo - 1 : h->ghost_valid - 1;
+            s += 1;
+        }
+        if (n < cap) seq[n] = code;
+        n++;
+    }
+    h->ghost_valid = gv0;
+    return n;
+}
+
 extern "C" int wt_step(wt_handle *h, int nsteps, double tau, double u0)
 {
     WT_TRY(check_steppable(h, nsteps, tau, u0));

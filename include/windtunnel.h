@@ -151,6 +151,11 @@ int wt_init_equilibrium(wt_handle *h, double u0);
  * fields (rho,ux,uy) that the reference writes into texC (html:357-359). */
 int wt_step(wt_handle *h, int nsteps, double tau, double u0);
 
+/* How `nsteps` steps would be taken from the handle's present state, without taking them: seq[i] = +k for a fused pass of k steps, 1 for a
+ * single step, -1 for a single step that refreshes the ghost columns first; returns the length of the sequence (at most `cap` entries are
+ * written).  Slab handles of one tunnel answer alike — the property the collective exchange over RCCL rests on. */
+int wt_plan_steps(wt_handle *h, int nsteps, double tau, int *seq, int cap);
+
 /* As wt_step, bracketed by HIP events on the stream the step kernels run on;
  * blocks, and returns the elapsed device time in milliseconds. */
 int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, float *elapsed_ms);

@@ -169,3 +169,57 @@ def test_rccl_plumbing_selftest(pkg):
     pkg.Engine.comm_selftest(0, 4096)
     ident = pkg.Engine.comm_unique_id()
     assert len(ident) == 128 and any(ident)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_every_rank_plans_the_same_schedule(pkg, dtype):
+    """Over RCCL each rank decides alone when to run a fused pass, how long, and when to refresh its ghost columns, and the exchange is
+    collective: all ranks of a tunnel must decide alike, whatever their own width (edge slabs hold one ghost zone, interior slabs two,
+    and a split that does not divide leaves widths one column apart).  wt_plan_steps returns those decisions without taking them."""
+    import numpy as np
+    cases = [(4096, 4096, 8, 16), (4096, 4096, 8, 17), (4096, 4096, 4, 16), (4096, 4096, 2, 9), (1984, 4096, 4, 16), (2304, 4096, 2, 2),
+             (2304, 4096, 2, 1), (2304, 4096, 3, 3), (4000, 4096, 7, 16), (4099, 2048, 8, 5), (1100, 4096, 2, 16), (16384, 4096, 8, 16)]
+    for nx, ny, nranks, halo in cases:
+        if dtype == "float64" and nx * ny > 4096 * 4096:
+            continue
+        es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+        try:
+            mask = np.zeros((ny, nx), np.uint8)
+            for e in es:
+                e.set_mask(mask); e.init_equilibrium(0.06)
+            depths = {(e.get_option("fuse_active"), e.get_option("fuse_depth")) for e in es}
+            assert len(depths) == 1, (nx, ny, nranks, halo, depths)
+            for nsteps in (1, 4, 5, 17, 33, 100):
+                plans = [tuple(e.plan_steps(nsteps, 0.58)) for e in es]
+                assert len(set(plans)) == 1, (nx, ny, nranks, halo, nsteps, plans)
+                p = plans[0]
+                assert sum(abs(k) if k != -1 else 1 for k in p) == nsteps
+                if halo >= 4 and nsteps > halo and es[0].get_option("fuse_active"):
+                    assert p.count(-1) >= 1 and any(k >= 2 for k in p)            # refreshes AND fused passes (an initial state's ghosts last `halo` steps)
+        finally:
+            for e in es:
+                e.close()
+
+
+def test_the_planned_schedule_is_the_one_that_runs(pkg):
+    """wt_plan_steps against what wt_step_group then does (passes and single steps counted by the library)."""
+    import numpy as np
+    nx, ny, nranks, halo = 2048, 512, 4, 16
+    mask = pkg.geometry.build_geometry(nx, ny, 7.0, None, "naca2412").mask
+    es = [pkg.Engine(nx, ny, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_option("fuse_steps", 2)
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        for nsteps in (50, 7, 33):
+            plan = es[0].plan_steps(nsteps, 0.58)
+            assert all(e.plan_steps(nsteps, 0.58) == plan for e in es)
+            before = [(e.get_option("passes"), e.get_option("single_steps")) for e in es]
+            pkg.Engine.step_group(es, nsteps, 0.58, 0.06)
+            for e, (p0, s0) in zip(es, before):
+                assert e.get_option("passes") - p0 == sum(1 for k in plan if k >= 2)
+                assert e.get_option("single_steps") - s0 == sum(1 for k in plan if k in (1, -1))
+    finally:
+        for e in es:
+            e.close()
