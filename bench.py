@@ -80,6 +80,10 @@ def parse_args():
     ap.add_argument("--fast-math", type=int, default=-1, choices=[-1, 0, 1],
                     help="the OPT-IN contracted collision (fused multiply-adds, v_rcp): -1 (default) = the bit-exact kernels print the line and the "
                          "contracted ones are timed beside them as roofline.contracted; 0 = skip that; 1 = the whole run uses them (NOT bit-exact)")
+    ap.add_argument("--pmc-traffic", type=int, default=1, choices=[0, 1],
+                    help="1 (default, one GPU only): before the timed run, measure this workload's HBM traffic per launch in this session — two short "
+                         "child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` — and use it for roofline.traffic / frac; "
+                         "0, or when rocprofv3 is not available: the entry of profiles/pmc_traffic.json (measured in another run), if there is one")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -136,6 +140,77 @@ def measured_traffic(workload_key):
     except Exception:
         return None
     return e if e and "hbm_bytes_per_launch" in e else None
+
+
+def pmc_traffic_this_session(args):
+    """HBM bytes per launch of the dominant kernel(s), measured NOW on this box: two short child runs of this same script and workload under
+    rocprofv3, one per counter (they do not fit one pass; MI355X_MICROARCH.md HBM section: FETCH_SIZE KB x 1024 x 2 on gfx950, WRITE_SIZE KB x
+    1024).  Runs before this process touches the GPU; the children are started with the interpreter itself behind `--`.  Returns None on any
+    failure (no rocprofv3, no counters, a profiler already attached to this process)."""
+    import glob
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "48", "--warmup", "12", "--cpu-steps", "0", "--fast-math", "0",
+             "--pmc-traffic", "0", "--nx", str(args.nx), "--ny", str(args.ny), "--dtype", args.dtype, "--shape", args.shape, "--aoa", str(args.aoa),
+             "--u0", str(args.u0), "--tau", str(args.tau), "--fuse", str(args.fuse), "--fuse-chunk", str(args.fuse_chunk),
+             "--fuse-depth", str(args.fuse_depth)]
+    if args.dat:
+        child += ["--dat", args.dat]
+    if args.fast_math == 1:
+        child[child.index("--fast-math") + 1] = "1"
+    per_kernel = {}
+    tmp = tempfile.mkdtemp(prefix="wt_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([rocprof, "--pmc", counter, "-d", out, "-o", "c", "--"] + child, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=240)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            con = sqlite3.connect(dbs[0])
+            acc = {}
+            for kname, disp, val in con.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name = ?", (counter,)):
+                k = re.sub(r"\(.*", "", kname).replace("void ", "").replace(", ", ",")
+                acc.setdefault(k, {}).setdefault(disp, 0.0)
+                acc[k][disp] += val
+            for k, d in acc.items():
+                per_kernel.setdefault(k, {})[counter] = sum(d.values()) / len(d)
+    except Exception:      # noqa: BLE001 - the file entry (or null) stands in
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return per_kernel
+
+
+def select_traffic(per_kernel, fused, depth):
+    """Sum the dominant kernels of one launch (pass) out of pmc_traffic_this_session()'s table."""
+    if not per_kernel:
+        return None
+    if not fused:
+        use = lambda k: k.startswith("wt::k_step<") and ",false," in k
+        what = "wt::k_step<T,false,...> (non-emitting step)"
+    elif depth >= 3:
+        use = lambda k: (k.startswith("wt::k_march3<") and f",{depth},false," in k) or k.startswith("wt::k_halo4<" if depth == 4 else "wt::k_halo3<")
+        what = f"one pass = wt::k_halo{4 if depth == 4 else 3} + wt::k_march3<T,S,{depth},false,FD>"
+    else:
+        use = lambda k: (k.startswith("wt::k_march<") and ",false," in k) or k.startswith("wt::k_halo_from_seams")
+        what = "one pass = wt::k_halo_from_seams + wt::k_march<T,S,false,FD>"
+    fetch = sum(v.get("FETCH_SIZE", 0.0) for k, v in per_kernel.items() if use(k)) * 1024 * 2
+    write = sum(v.get("WRITE_SIZE", 0.0) for k, v in per_kernel.items() if use(k)) * 1024
+    if fetch <= 0 or write <= 0:
+        return None
+    return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write, "kernel": what,
+            "measured": "this session, this box: two child runs of this command (48 timed steps) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
+                        "just before the timed run",
+            "source": "rocprofv3 counters, FETCH_SIZE KB x1024 x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KB x1024"}
 
 
 def die(rank, device, what, err=None):
@@ -265,6 +340,9 @@ def main():
             raise SystemExit(2)
         args.gpus = world
 
+    # same-session HBM traffic (children under rocprofv3), before this process touches the GPU
+    session_traffic = pmc_traffic_this_session(args) if (world == 1 and args.pmc_traffic == 1 and args.local_slabs == 0) else None
+
     import datetime
     import numpy as np
     import torch
@@ -378,7 +456,8 @@ def main():
         main_kernel = "wt::k_march3 (THREE steps per pass, body / inlet / outlet inside; + wt::k_halo3 per pass)"
     elif fused:
         main_kernel = "wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)"
-    traffic = None if distributed else measured_traffic(key + (("_march4" if steps_per_launch == 4 else "_march3" if steps_per_launch == 3 else "_march") if fused else ""))
+    traffic = None if distributed else (select_traffic(session_traffic, fused, steps_per_launch) or
+                                        measured_traffic(key + (("_march4" if steps_per_launch == 4 else "_march3" if steps_per_launch == 3 else "_march") if fused else "")))
     r = roofline_entry(main_kernel, bpl * sites_per_launch * steps_per_launch, launch_ms, traffic)
     # `achieved` / `frac` are the REAL HBM rate (rocprofv3 counters of this workload, profiles/pmc_traffic.json) over this run's launch time,
     # or null when this workload was never profiled — never the "effective" figure, which a multi-step pass can push beyond the peak.
@@ -398,8 +477,8 @@ def main():
                 "frac": None if achieved is None else achieved / HBM_PEAK_GBPS,
                 "bound_note": ("vector-instruction issue (SQ_ACTIVE_INST_VALU ~ 65 % of the SIMD time at 2 waves per SIMD); the HBM figures "
                                "say how far below the memory roof that leaves the kernel" if fused else "HBM bandwidth"),
-                "achieved_basis": ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/pmc_traffic.json) / this run's launch time"
-                                   if achieved is not None else "no counter entry for this workload in profiles/pmc_traffic.json"),
+                "achieved_basis": ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (see traffic_source.measured) / this run's launch time"
+                                   if achieved is not None else "no counters: rocprofv3 unavailable (or --pmc-traffic 0) and no entry for this workload in profiles/pmc_traffic.json"),
                 "traffic": r["traffic"], "traffic_source": r["traffic_source"], "counter_gbps": r["counter_gbps"],
                 "compulsory_gbps": compulsory, "compulsory_frac": compulsory / HBM_PEAK_GBPS,
                 "effective_gbps": r["effective_gbps"], "effective_frac": r["effective_frac"],
@@ -426,7 +505,7 @@ def main():
             eng.step(4, args.tau, args.u0)
             n1 = max(10, min(40, args.steps))
             ms1 = eng.step_timed(n1, args.tau, args.u0) / n1
-            s = roofline_entry("wt::k_step (one step per launch)", bpl * sites_per_launch, ms1, measured_traffic(key))
+            s = roofline_entry("wt::k_step (one step per launch)", bpl * sites_per_launch, ms1, measured_traffic(key))       # (file entry: measured in another run)
             s["achieved"] = s["counter_gbps"]                 # one step per launch: effective == compulsory
             s["frac"] = None if s["achieved"] is None else s["achieved"] / HBM_PEAK_GBPS
             s["mlups"] = sites / (ms1 * 1e-3) / 1e6

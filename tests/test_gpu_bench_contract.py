@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def _run(*extra):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "1024", "--ny", "512", "--steps", "20",
-                          "--warmup", "3", "--cpu-steps", "1", *extra], capture_output=True, text=True, timeout=600, check=True)
+                          "--warmup", "3", "--cpu-steps", "1", *(() if "--pmc-traffic" in extra else ("--pmc-traffic", "0")), *extra],
+                         capture_output=True, text=True, timeout=600, check=True)
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout
     return json.loads(lines[0])
@@ -32,7 +33,7 @@ def test_bench_json_contract():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0            # un-fused on this small lattice: k_step
-    # no rocprofv3 counter entry exists for this lattice: `frac` is null, never the effective figure
+    # (--pmc-traffic 0 and) no rocprofv3 counter entry exists for this lattice: `frac` is null, never the effective figure
     assert r["frac"] is None and r["achieved"] is None and r["traffic"] is None
     assert 0 < r["compulsory_frac"] <= 1.0 and abs(r["compulsory_frac"] - r["compulsory_gbps"] / r["peak"]) < 1e-12
     # value and the throughput figure describe the same run: MLUPS * 72 B = GB/s (up to wall-vs-device timing)
@@ -56,9 +57,23 @@ def test_bench_fused_flag_and_fp64():
     assert d["dtype"] == "f64" and d["roofline"]["algorithmic_bytes_per_launch"] == 144 * 1024 * 512
 
 
+def test_bench_measures_its_traffic_in_the_same_session():
+    """Default behaviour: two short child runs under rocprofv3 --pmc measure the workload's HBM bytes per launch on THIS box just before the timed
+    run, for any lattice — here one that has no entry in profiles/pmc_traffic.json."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    d = _run("--pmc-traffic", "1", "--fuse", "2")
+    r = d["roofline"]
+    assert r["frac"] is not None and 0.05 < r["frac"] <= 1.0, r
+    assert "this session" in r["traffic_source"]["measured"]
+    # a four-step pass over 1024 x 512 fp32 moves at least one lattice read + one lattice write, and far less than four single steps
+    assert 72 * 1024 * 512 <= r["traffic"] <= 2.5 * 72 * 1024 * 512, r["traffic"]
+
+
 def test_bench_default_frac_is_counter_based_and_below_one():
     """The default workload has a counter entry (profiles/pmc_traffic.json): frac = measured HBM bytes / this run's time <= 1."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-steps", "0"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--cpu-steps", "0", "--pmc-traffic", "0"],
                          capture_output=True, text=True, timeout=600, check=True)
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
     r = d["roofline"]

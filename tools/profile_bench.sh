@@ -10,9 +10,9 @@ mkdir -p $out
 export TMPDIR=/tmp
 for mode in march4 march3 march nofuse; do
     fuse="--fuse -1"; [ $mode = nofuse ] && fuse="--fuse 0"; [ $mode = march ] && fuse="--fuse-depth 2"; [ $mode = march3 ] && fuse="--fuse-depth 3"
-    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${mode}_trace -o t -- python3 bench.py $fuse --cpu-steps 0 "$@" > $out/${mode}_trace.log 2>&1
-    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $out/${mode}_fetch -o f -- python3 bench.py $fuse --cpu-steps 0 --steps 48 --warmup 12 "$@" > $out/${mode}_fetch.log 2>&1
-    timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $out/${mode}_write -o w -- python3 bench.py $fuse --cpu-steps 0 --steps 48 --warmup 12 "$@" > $out/${mode}_write.log 2>&1
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${mode}_trace -o t -- python3 bench.py $fuse --pmc-traffic 0 --cpu-steps 0 "$@" > $out/${mode}_trace.log 2>&1
+    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $out/${mode}_fetch -o f -- python3 bench.py $fuse --pmc-traffic 0 --cpu-steps 0 --steps 48 --warmup 12 "$@" > $out/${mode}_fetch.log 2>&1
+    timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $out/${mode}_write -o w -- python3 bench.py $fuse --pmc-traffic 0 --cpu-steps 0 --steps 48 --warmup 12 "$@" > $out/${mode}_write.log 2>&1
     echo "$mode done"
 done
 find $out -name "*.db" -size +60M -delete      # the merge-back limit is 64 MiB

@@ -7,9 +7,9 @@ bash tools/profile_bench.sh r03 > $out/profile_bench.log 2>&1
 for cfg in "4096 4096" "4096 2048"; do
   set -- $cfg
   tag=f64_$1x$2
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t -- python3 bench.py --dtype float64 --nx $1 --ny $2 --cpu-steps 0 > $out/${tag}_trace.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t -- python3 bench.py --pmc-traffic 0 --dtype float64 --nx $1 --ny $2 --cpu-steps 0 > $out/${tag}_trace.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 200 rocprofv3 --pmc $c -d $out/${tag}_$c -o c -- python3 bench.py --dtype float64 --nx $1 --ny $2 --cpu-steps 0 --steps 48 --warmup 12 > $out/${tag}_$c.log 2>&1 || echo "$tag $c failed"
+    timeout -k 10 200 rocprofv3 --pmc $c -d $out/${tag}_$c -o c -- python3 bench.py --pmc-traffic 0 --dtype float64 --nx $1 --ny $2 --cpu-steps 0 --steps 48 --warmup 12 > $out/${tag}_$c.log 2>&1 || echo "$tag $c failed"
   done
 done
 i=0
@@ -20,7 +20,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ" \
            "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_WRITE_REQ TCP_TCP_TA_DATA_STALL_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $grp -d $out/sq_$i -o c -- python3 bench.py --cpu-steps 0 --steps 48 --warmup 12 > $out/sq_$i.log 2>&1 || echo "group $i failed"
+  timeout -k 10 200 rocprofv3 --pmc $grp -d $out/sq_$i -o c -- python3 bench.py --pmc-traffic 0 --cpu-steps 0 --steps 48 --warmup 12 > $out/sq_$i.log 2>&1 || echo "group $i failed"
 done
 python3 bench.py > $out/bench.json 2> $out/bench.err
 python3 bench.py --steps 20 --warmup 5 > $out/bench_driver_args.json 2> /dev/null

@@ -7,9 +7,9 @@ bash tools/profile_bench.sh r03e --fast-math 0 > $out/profile_bench.log 2>&1
 for cfg in "4096 4096" "4096 2048"; do
   set -- $cfg
   tag=f64_$1x$2
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t -- python3 bench.py --dtype float64 --nx $1 --ny $2 --cpu-steps 0 > $out/${tag}_trace.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o t -- python3 bench.py --pmc-traffic 0 --dtype float64 --nx $1 --ny $2 --cpu-steps 0 > $out/${tag}_trace.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 200 rocprofv3 --pmc $c -d $out/${tag}_$c -o c -- python3 bench.py --dtype float64 --nx $1 --ny $2 --cpu-steps 0 --steps 48 --warmup 12 > $out/${tag}_$c.log 2>&1 || echo "$tag $c failed"
+    timeout -k 10 200 rocprofv3 --pmc $c -d $out/${tag}_$c -o c -- python3 bench.py --pmc-traffic 0 --dtype float64 --nx $1 --ny $2 --cpu-steps 0 --steps 48 --warmup 12 > $out/${tag}_$c.log 2>&1 || echo "$tag $c failed"
   done
 done
 : > $out/width_sweep.txt
