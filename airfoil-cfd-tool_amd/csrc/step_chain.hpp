@@ -239,20 +239,22 @@ struct ChainUnit {
 // ------------------------------------------------------------------------------------------------
 // the marching kernel: solo units (step_march3.hpp) and chain blocks in one launch
 // ------------------------------------------------------------------------------------------------
-#ifdef WT_UNIT_CLOCKS         // diagnostic build (tools/unit_clocks.py): how long does every unit of a pass take?  [unit] = {start, end} (s_memtime)
-__device__ unsigned long long g_unit_clk[2 * 16384];
+// How long does every unit of a pass take?  Tuning passes (tune_fuse_plan in windtunnel.hip; tools/unit_clocks.py) hand a buffer over:
+// [unit] = {start, end} in s_memtime ticks.  Ordinary passes carry a null pointer and pay one scalar read of the clock.
 struct UnitClock {
+    unsigned long long *clk;
     int u, lane;
     unsigned long long t0;
-    __device__ UnitClock(int u_, int lane_) : u(u_), lane(lane_), t0(__builtin_amdgcn_s_memtime()) {}
+    __device__ UnitClock(unsigned long long *clk_, int u_, int lane_) : clk(clk_), u(u_), lane(lane_), t0(clk_ ? __builtin_amdgcn_s_memtime() : 0ULL) {}
     __device__ ~UnitClock()
     {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        if (lane == 0 && u < 16384) { g_unit_clk[2 * u] = t0; g_unit_clk[2 * u + 1] = t1; }
+        if (clk) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            if (lane == 0) { clk[2 * u] = t0; clk[2 * u + 1] = t1; }
+        }
     }
 };
-#endif
 
 template <typename T, int S, int DEPTH, bool EMIT, int FD>
 __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
@@ -268,9 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     const int ia = __builtin_amdgcn_readfirstlane(un.ia), ib = __builtin_amdgcn_readfirstlane(un.ib);
     const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
     if (ib <= ia) return;
-#ifdef WT_UNIT_CLOCKS
-    UnitClock unit_clock(u, lane);
-#endif
+    UnitClock unit_clock(p.clk, u, lane);
     const int row0 = w * M3_WIN;
     const int j0 = row0 + lane * S;
     const bool far_win = (w == 0) || (row0 + M3_WIN >= g.ny);
@@ -411,9 +411,10 @@ static inline void chain_blocks(MarchPlan &pl, const uint8_t *wcls, const Geom &
 // of four either one chain block or four solo units (the last solo group of the list is padded with empty units).
 // solo: columns iterated beyond the unit's own, outlet extra, slow-down of a unit that runs the general loop (inlet / outlet / body in its footprint:
 // class tests and scalar branches per column), cost of an iteration on a column beyond the tunnel's end; chain: per-unit overheads in columns
-struct ChainCost { double over, tail, ov_inner, ov_outer, beta, outside; int max_chain; };
+// (solid: what a column of an all-solid tile costs beyond a plain one — such tiles skip the collision, yet their units run the general loop)
+struct ChainCost { double over, tail, ov_inner, ov_outer, beta, outside; int max_chain; double solid; };
 static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &g, int win, long target_units, double alpha, const MarchRange &r, int min_last,
-                                               int max_len, int depth, const ChainCost &cc)
+                                               int max_len, int depth, const ChainCost &cc, const float *colw = nullptr)
 {
     MarchPlan pl;
     const int nwin = march_nwin(g.ny, win), ld = g.nxl + 2, pad = depth == 4 ? 3 : 2;
@@ -431,7 +432,8 @@ static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &
         for (int k = 0; k < n; k++) {
             const int x = r.i_begin - E + k, gi = x + g.gi0;
             double cost = cc.outside;
-            if (gi >= 0 && gi < g.nx_g) cost = (x >= -1 && x <= g.nxl && c[x] != WC_FAST) ? 1.0 + alpha : 1.0;
+            if (gi >= 0 && gi < g.nx_g) cost = (x >= -1 && x <= g.nxl && c[x] != WC_FAST) ? 1.0 + (c[x] == WC_SOLID ? cc.solid : alpha) : 1.0;
+            if (colw && x >= -1 && x <= g.nxl) cost *= colw[(size_t)w * ld + x + 1];      // measured correction (tune_fuse_plan)
             Cw[k + 1] = Cw[k] + cost;
         }
         int *Nw = &NF[(size_t)w * (g.nxl + 3)];

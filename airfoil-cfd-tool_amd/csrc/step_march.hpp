@@ -290,6 +290,7 @@ struct MarchParams {
     T tau;
     T U0;
     int rev;
+    unsigned long long *clk = nullptr;   // tuning passes only (tune_fuse_plan): [unit] = {start, end} of every unit in s_memtime ticks
 };
 
 // S consecutive rows of one column and direction, held by one lane
@@ -1053,11 +1054,11 @@ static inline MarchPlan build_march_plan(const uint8_t *wcls, const Geom &g, int
 // for its neighbours' sake (pipeline fill and drain: 2.7 iterations of a three-step pass, 4.5 of a four-step one), which in the body zone
 // are body columns too (per-unit clocks, tools/unit_clocks.py: with the cut by owned columns a two-column body unit of the bench mask took
 // 1.55 x as long as a ten-column plain one and set the pace of the whole launch).  time(ia, ib) = C(ib + over / 2) - C(ia - over / 2) with
-// C the running cost of the window's columns (a FAST column 1, any other 1 + alpha, nothing beyond the tunnel's ends) and `tail` more
+// C the running cost of the window's columns (a FAST column 1, a column of an all-solid tile 1 + alpha_solid, any other 1 + alpha, nothing beyond the tunnel's ends) and `tail` more
 // for the unit that also emits the outlet column; the smallest t for which every window cut greedily into units of time <= t gives at
 // most target_units in total is found by bisection.
 static inline MarchPlan build_march_plan_timed(const uint8_t *wcls, const Geom &g, int win, long target_units, double alpha, const MarchRange &r, int min_last,
-                                               int max_len, double over, double tail)
+                                               int max_len, double over, double tail, double alpha_solid, const float *colw = nullptr)
 {
     MarchPlan pl;
     const int nwin = march_nwin(g.ny, win), ld = g.nxl + 2;
@@ -1074,7 +1075,8 @@ static inline MarchPlan build_march_plan_timed(const uint8_t *wcls, const Geom &
         for (int k = 0; k < n; k++) {
             const int x = r.i_begin - E + k, gi = x + g.gi0;
             double cost = 0.0;
-            if (gi >= 0 && gi < g.nx_g) cost = (x >= -1 && x <= g.nxl && c[x] != WC_FAST) ? 1.0 + alpha : 1.0;
+            if (gi >= 0 && gi < g.nx_g) cost = (x >= -1 && x <= g.nxl && c[x] != WC_FAST) ? 1.0 + (c[x] == WC_SOLID ? alpha_solid : alpha) : 1.0;
+            if (colw && x >= -1 && x <= g.nxl) cost *= colw[(size_t)w * ld + x + 1];      // measured correction (tune_fuse_plan)
             Cw[k + 1] = Cw[k] + cost;
         }
     }

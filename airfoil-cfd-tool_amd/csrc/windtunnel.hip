@@ -88,6 +88,7 @@ struct wt_handle {
     void *partials_host = nullptr;
     hipStream_t s_compute = nullptr, s_comm = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_state = nullptr, ev_halo = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;      // around the marching kernel of a tuning pass
     bool mask_set = false, inited = false;
     bool macro_stale = false;    // wt_write_f replaced the populations: (rho,ux,uy) describe an older state until a step emits them
     int ghost_valid = 0;         // ghost columns still exact (both sides)
@@ -132,6 +133,17 @@ struct wt_handle {
     bool fast_math = false;              // option "fast_math": contracted collision in the marching kernels (opt-in; tolerance, not bit-equality)
     bool chain = true;                   // option "chain": plain-fluid workgroups share their units' edge columns (step_chain.hpp)
     int n_chain_units = 0;
+    // the plan's units on the host, and their refinement by measured unit times (tune_fuse_plan)
+    std::vector<MarchUnit> host_units;
+    long plan_target = 0;
+    bool tune = true;                    // option "tune"
+    bool plan_tuned = false;
+    int tune_rounds = 0;                 // refinements tried for the present plan
+    double tune_gain = 0.0;              // makespan of the modelled plan / makespan of the plan kept (unit clocks)
+    unsigned long long *d_clk = nullptr;  // unit clocks of tuning passes: two records of n_units {start, end}
+    size_t clk_cap = 0;
+    bool clk_on = false;
+    size_t clk_off = 0;
 };
 
 static const int kReduceBlocks = 1024;
@@ -175,6 +187,7 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     HIP_TRY(hipSetDevice(device));
 
     wt_handle *h = new (std::nothrow) wt_handle();
+    if (h && getenv("WT_TUNE")) h->tune = atoi(getenv("WT_TUNE")) != 0;      // experiments; the option "tune" is the interface
     if (!h) return fail(WT_ERR_OOM, "host allocation failed");
     h->nx_g = nx_g; h->ny = ny; h->dtype = dtype; h->device = device;
     h->rank = rank; h->nranks = nranks;
@@ -228,6 +241,8 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     CREATE_TRY(hipStreamCreateWithPriority(&h->s_comm, hipStreamNonBlocking, hi));
     CREATE_TRY(hipEventCreate(&h->ev_a));
     CREATE_TRY(hipEventCreate(&h->ev_b));
+    CREATE_TRY(hipEventCreate(&h->ev_t0));
+    CREATE_TRY(hipEventCreate(&h->ev_t1));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_halo, hipEventDisableTiming));
     CREATE_TRY(hipMemsetAsync(h->f[0], 0, lat_bytes, h->s_compute));
@@ -288,11 +303,14 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->seams) (void)hipFree(h->seams);
     if (h->seam_plain) (void)hipFree(h->seam_plain);
     if (h->d_units) (void)hipFree(h->d_units);
+    if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->d_nbad) (void)hipFree(h->d_nbad);
     if (h->partials) (void)hipFree(h->partials);
     if (h->partials_host) (void)hipHostFree(h->partials_host);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
+    if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     if (h->ev_state) (void)hipEventDestroy(h->ev_state);
     if (h->ev_halo) (void)hipEventDestroy(h->ev_halo);
     if (h->s_compute) (void)hipStreamDestroy(h->s_compute);
@@ -354,6 +372,61 @@ static void free_march_tables(wt_handle *h)
     h->n_win = 0;
     h->device_bytes -= h->march_table_bytes;
     h->march_table_bytes = 0;
+}
+
+// The unit list of the handle's tables (host_wcls, march_s, march_depth, plan_target); colw: per (window, column) corrections of the column
+// costs measured by tune_fuse_plan, or null.
+static bool plan_by_time(const wt_handle *h)
+{
+    static const int timed = getenv("WT_PLAN_TIMED") ? atoi(getenv("WT_PLAN_TIMED")) : 1;
+    return h->fuse_chunk <= 0 && timed;
+}
+static void cut_units(wt_handle *h, const float *colw, MarchPlan *out)
+{
+    const Geom &g = h->g;
+    const int depth = h->march_depth, win = 64 * h->march_s;
+    const long target = h->plan_target;
+    const MarchRange r = depth >= 3 ? march_range3(g, depth) : march_range(g);
+    // four steps per pass: class masks cover ib - ia + 6 columns, and the last unit of a window marches at least two
+    // cost of a column that is not plain fluid, in plain columns: 1 + alpha; `over`: columns a unit iterates over beyond its own (pipeline
+    // fill and drain of a `depth`-step pass); `tail`: the outlet column's extra stages — see build_march_plan_timed
+    static const double alpha = getenv("WT_ALPHA") ? atof(getenv("WT_ALPHA")) : 1.6;
+    static const double alpha_solid = getenv("WT_ALPHA_SOLID") ? atof(getenv("WT_ALPHA_SOLID")) : alpha;
+    static const int timed = getenv("WT_PLAN_TIMED") ? atoi(getenv("WT_PLAN_TIMED")) : 1;
+    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
+    const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
+    const bool by_time = plan_by_time(h);
+    const bool chain = depth >= 3 && h->chain;
+    // chain overheads in columns, from per-unit clocks on a 544-column lattice (tools/unit_clocks.py): a four-step chain unit of 8.5 columns takes as
+    // long as 10.5 solo iterations, a three-step one as 9.9
+    static const double beta = getenv("WT_BETA") ? atof(getenv("WT_BETA")) : 1.25;
+    static const int max_chain = getenv("WT_MAX_CHAIN") ? atoi(getenv("WT_MAX_CHAIN")) : 160;
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, beta, 0.6, max_chain, alpha_solid};
+    MarchPlan pl = !by_time ? build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, timed ? alpha : 4.0, &r, min_last, max_len, chain ? 4 : 1)
+                   : chain  ? build_chain_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, depth, cc, colw)
+                            : build_march_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, over, tail, alpha_solid, colw);
+    if (chain && !by_time) chain_blocks(pl, h->host_wcls.data(), g, depth, true);      // the fuse_chunk option: blocks of four consecutive units of the cut by columns
+    *out = std::move(pl);
+}
+
+static int upload_units(wt_handle *h, const MarchPlan &pl)
+{
+    h->n_chain_units = 0;
+    for (const MarchUnit &u : pl.units) h->n_chain_units += (u.flags & MU_CHAIN) != 0;
+    const size_t total = pl.units.size();
+    h->n_units = (int)total;
+    h->fuse_chunk_used = pl.chunk;
+    h->host_units = pl.units;
+    if (total == 0) return WT_OK;
+    if (total > h->units_cap) {
+        if (h->d_units) { HIP_TRY(hipFree(h->d_units)); h->d_units = nullptr; h->units_cap = 0; }
+        const size_t cap = total + total / 4 + 64;
+        HIP_TRY(hipMalloc((void **)&h->d_units, cap * sizeof(MarchUnit)));
+        h->units_cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_units, pl.units.data(), total * sizeof(MarchUnit), hipMemcpyHostToDevice, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    return WT_OK;
 }
 
 // Classes, bounce codes and the unit lists of the current mask for windows of 64 * sites rows.  Everything but the
@@ -425,41 +498,12 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     HIP_TRY(hipMemcpyAsync(h->host_wcls.data(), h->wcls, wbytes, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
 
+    h->plan_target = target;
+    h->plan_tuned = false;
+    MarchPlan pl;
+    cut_units(h, nullptr, &pl);
+    WT_TRY(upload_units(h, pl));
     const MarchRange r = depth >= 3 ? march_range3(g, depth) : march_range(g);
-    // four steps per pass: class masks cover ib - ia + 6 columns, and the last unit of a window marches at least two
-    // cost of a column that is not plain fluid, in plain columns: 1 + alpha; `over`: columns a unit iterates over beyond its own (pipeline
-    // fill and drain of a `depth`-step pass); `tail`: the outlet column's extra stages — see build_march_plan_timed
-    static const double alpha = getenv("WT_ALPHA") ? atof(getenv("WT_ALPHA")) : 1.6;
-    static const int timed = getenv("WT_PLAN_TIMED") ? atoi(getenv("WT_PLAN_TIMED")) : 1;
-    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
-    const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
-    const bool by_time = h->fuse_chunk <= 0 && timed;
-    const bool chain = depth >= 3 && h->chain;
-    // chain overheads in columns, from per-unit clocks on a 544-column lattice (tools/unit_clocks.py): a four-step chain unit of 8.5 columns takes as
-    // long as 10.5 solo iterations, a three-step one as 9.9
-    static const double beta = getenv("WT_BETA") ? atof(getenv("WT_BETA")) : 1.25;
-    static const int max_chain = getenv("WT_MAX_CHAIN") ? atoi(getenv("WT_MAX_CHAIN")) : 160;
-    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, beta, 0.6, max_chain};
-    MarchPlan pl = !by_time ? build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, timed ? alpha : 4.0, &r, min_last, max_len, chain ? 4 : 1)
-                   : chain  ? build_chain_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, depth, cc)
-                            : build_march_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, over, tail);
-    h->n_chain_units = 0;
-    if (chain) {
-        if (!by_time) chain_blocks(pl, h->host_wcls.data(), g, depth, true);      // the fuse_chunk option: blocks of four consecutive units of the cut by columns
-        for (const MarchUnit &u : pl.units) h->n_chain_units += (u.flags & MU_CHAIN) != 0;
-    }
-    const size_t total = pl.units.size();
-    if (total == 0) return WT_OK;
-    if (total > h->units_cap) {
-        if (h->d_units) { HIP_TRY(hipFree(h->d_units)); h->d_units = nullptr; h->units_cap = 0; }
-        const size_t cap = total + total / 4 + 64;
-        HIP_TRY(hipMalloc((void **)&h->d_units, cap * sizeof(MarchUnit)));
-        h->units_cap = cap;
-    }
-    HIP_TRY(hipMemcpyAsync(h->d_units, pl.units.data(), total * sizeof(MarchUnit), hipMemcpyHostToDevice, h->s_compute));
-    HIP_TRY(hipStreamSynchronize(h->s_compute));
-    h->n_units = (int)total;
-    h->fuse_chunk_used = pl.chunk;
     for (int w = 0; w < nwin; w++)
         for (int x = r.i_begin; x < r.i_end; x++) h->nonfast_tiles += h->host_wcls[(size_t)w * (g.nxl + 2) + x + 1] != WC_FAST;
     return WT_OK;
@@ -570,7 +614,8 @@ extern "C" int wt_debug_unit_clocks(wt_handle *h, unsigned long long *clk, int *
     WT_TRY(check_handle(h));
     HIP_TRY(hipDeviceSynchronize());
     const int n = h->n_units < cap ? h->n_units : cap;
-    HIP_TRY(hipMemcpyFromSymbol(clk, HIP_SYMBOL(wt::g_unit_clk), (size_t)2 * n * sizeof(unsigned long long)));
+    if (!h->d_clk) return fail(WT_ERR_STATE, "no pass has recorded unit clocks yet");
+    HIP_TRY(hipMemcpy(clk, h->d_clk, (size_t)2 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(units4, h->d_units, (size_t)n * sizeof(MarchUnit), hipMemcpyDeviceToHost));
     return n;
 }
@@ -616,6 +661,11 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->chain = value != 0.0;
         return rebuild_fuse_plan(h);
     }
+    if (strcmp(name, "tune") == 0) {
+        // measured refinement of the marching units before the first pass on a plan (tune_fuse_plan); 0 keeps the modelled cut
+        h->tune = value != 0.0;
+        return h->plan_tuned ? rebuild_fuse_plan(h) : WT_OK;
+    }
     if (strcmp(name, "fast_math") == 0) {
         if (value != 0.0 && h->dtype != WT_F32) return fail(WT_ERR_STATE, "fast_math is an fp32 option");
         h->fast_math = value != 0.0;
@@ -639,6 +689,9 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "chain") == 0) { *value = h->chain ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fast_math") == 0) { *value = h->fast_math ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "chain_units") == 0) { *value = h->fuse_ready ? h->n_chain_units : 0; return WT_OK; }     // units that run in chain blocks
+    if (strcmp(name, "tune") == 0) { *value = h->tune ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "tune_rounds") == 0) { *value = h->plan_tuned ? h->tune_rounds : 0; return WT_OK; }        // plans measured for the present mask
+    if (strcmp(name, "tune_gain") == 0) { *value = h->plan_tuned ? h->tune_gain : 0.0; return WT_OK; }          // makespan modelled plan / kept plan
     if (strcmp(name, "single_steps") == 0) { *value = (double)h->single_steps; return WT_OK; }   // whole steps taken by k_step since the last init / write_f
     if (strcmp(name, "passes") == 0) { *value = (double)h->passes; return WT_OK; }
     if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
@@ -980,6 +1033,17 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     return fd ? step_pair_fused_t<float, 2, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 2, 0>(h, tau, u0, emit);
 }
 
+static int ensure_clocks(wt_handle *h)
+{
+    const size_t need = (size_t)4 * (size_t)h->n_units + 8;       // two records
+    if (need > h->clk_cap) {
+        if (h->d_clk) { HIP_TRY(hipFree(h->d_clk)); h->d_clk = nullptr; h->clk_cap = 0; }
+        HIP_TRY(hipMalloc((void **)&h->d_clk, need * sizeof(unsigned long long)));
+        h->clk_cap = need;
+    }
+    return WT_OK;
+}
+
 // Three steps in one pass (step_march3.hpp), or two on the same tables (depth = 2: what a step count leaves over).
 // A = f[cur] (time t), B = f[1-cur] (receives time t + depth).
 template <typename T, int S, int FD>
@@ -1000,6 +1064,10 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)(h->passes & 1);
+    if (h->clk_on) p.clk = h->d_clk + h->clk_off;
+#ifdef WT_UNIT_CLOCKS         // diagnostic build (tools/unit_clocks.py): every pass records its units
+    else { WT_TRY(ensure_clocks(h)); p.clk = h->d_clk; }
+#endif
     hipStream_t st = h->s_compute;
     if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
         if (h->march_depth == 4) {      // the plan's tables are those of the four-step pass, whatever this pass advances
@@ -1014,6 +1082,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
         }
     }
     p.units = h->d_units; p.nunits = h->n_units;
+    if (h->clk_on) HIP_TRY(hipEventRecord(h->ev_t0, st));       // tuning passes: the marching kernel alone is timed
     if (p.nunits > 0) {
         const dim3 grid((unsigned)((p.nunits + 3) / 4));
         if (depth == 4) {
@@ -1030,6 +1099,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
         }
     }
     HIP_TRY(hipGetLastError());
+    if (h->clk_on) HIP_TRY(hipEventRecord(h->ev_t1, st));
     h->cur = 1 - h->cur;
     h->steps_done += depth;
     h->passes += 1;
@@ -1074,6 +1144,125 @@ static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
     return step_pair_fused(h, tau, u0, emit);
 }
 
+// Measure, then cut again.  The cut by time rests on a model of what a column costs (cut_units), and a launch takes as long as its
+// slowest unit; how good the model is depends on the mask and on the slab (the piece of the body a slab of an 8-way split holds ran 15 %
+// behind its plain units with constants fitted on the whole lattice: tools/r3_slab_costs.py).  So before the first pass on a new plan the
+// library times the units themselves: two passes (one per launch order) from the present state into the lattice nobody reads, with the
+// kernel stamping every unit's start and end (MarchParams::clk); a solo unit that ran r times as long as the median chain unit (or the
+// median unit, where no chain fits) has the cost of its own columns multiplied by r^0.6, the columns are cut again, and after a few rounds
+// the plan with the shortest measured makespan is kept (the modelled one if nothing beat it).  The populations are not touched: the
+// passes write f[1 - cur] and the scratch tables, the handle's counters are put back, and only the seam buffer is marked stale.
+// The cut changes no result — every plan computes the same bits (tests/test_gpu_fused.py runs tuned and untuned plans against the oracle).
+static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k);
+static int tune_fuse_plan(wt_handle *h, double tau, double u0)
+{
+    h->plan_tuned = true;
+    h->tune_rounds = 0;
+    h->tune_gain = 1.0;
+    static const int rounds = getenv("WT_TUNE_ROUNDS") ? atoi(getenv("WT_TUNE_ROUNDS")) : 6;
+    static const int trace = getenv("WT_TUNE_TRACE") ? atoi(getenv("WT_TUNE_TRACE")) : 0;
+    static const double damp = getenv("WT_TUNE_DAMP") ? atof(getenv("WT_TUNE_DAMP")) : 0.6;
+    if (!h->tune || rounds <= 0 || !h->fuse_ready || h->march_depth < 3 || !plan_by_time(h) || h->n_units < 8) return WT_OK;
+    const int k = fuse_pick(eff_depth(h), 1 << 20);
+    if (k < 2) return WT_OK;
+    const Geom &g = h->g;
+    const int ld = g.nxl + 2;
+    std::vector<float> colw((size_t)h->n_win * ld, 1.0f);
+    std::vector<MarchUnit> best = h->host_units;
+    double best_span = 0.0, first_span = 0.0;
+    std::vector<unsigned long long> clk;
+    std::vector<double> dur, chain_dur;
+    const int s_cur = h->cur, s_gv = h->ghost_valid;
+    const long long s_steps = h->steps_done, s_passes = h->passes;
+    bool have_best = false, uploaded_best = true;
+    for (int it = 0; it < rounds; it++) {
+        const int n = h->n_units;
+        WT_TRY(ensure_clocks(h));
+        HIP_TRY(hipMemsetAsync(h->d_clk, 0, (size_t)4 * n * sizeof(unsigned long long), h->s_compute));
+        // the plan's score: the time of its marching kernel, one launch per launch order (the units' clocks are per XCD and not
+        // comparable across units — only their durations are used); the very first launch is a warm-up
+        double span = 0.0;
+        for (int rep = (it == 0 ? -1 : 0); rep < 2; rep++) {
+            h->clk_on = true; h->clk_off = (size_t)2 * n * (rep < 0 ? 0 : rep);
+            h->passes = rep & 1;                               // the launch order alternates with the pass count
+            const int rc = step_fused(h, tau, u0, false, k);
+            h->clk_on = false;
+            h->cur = s_cur; h->ghost_valid = s_gv; h->steps_done = s_steps; h->passes = s_passes;
+            h->seams_valid = false;                            // the seam rows now describe the lattice that was thrown away
+            if (rc != WT_OK) return rc;
+            HIP_TRY(hipEventSynchronize(h->ev_t1));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1));
+            if (rep >= 0) span += 0.5 * (double)ms;
+        }
+        clk.resize((size_t)4 * n);
+        HIP_TRY(hipMemcpyAsync(clk.data(), h->d_clk, clk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->s_compute));
+        HIP_TRY(hipStreamSynchronize(h->s_compute));
+        dur.assign(n, 0.0);
+        chain_dur.clear();
+        double dmax = 0.0;
+        for (int u = 0; u < n; u++) {
+            for (int rep = 0; rep < 2; rep++) {
+                const unsigned long long t0 = clk[(size_t)2 * n * rep + 2 * u], t1 = clk[(size_t)2 * n * rep + 2 * u + 1];
+                if (t1 != 0) dur[u] += 0.5 * (double)(t1 - t0);          // (zero: an empty unit, padding of the last solo group)
+            }
+            dmax = std::max(dmax, dur[u]);
+        }
+        if (trace) {
+            std::vector<double> cd, sd;
+            int umax = 0;
+            for (int u = 0; u < n; u++) {
+                if (dur[u] <= 0.0) continue;
+                ((h->host_units[u].flags & MU_CHAIN) ? cd : sd).push_back(dur[u]);
+                if (dur[u] > dur[umax]) umax = u;
+            }
+            std::sort(cd.begin(), cd.end()); std::sort(sd.begin(), sd.end());
+            const MarchUnit &um = h->host_units[umax];
+            fprintf(stderr, "[wt tune] round %d: %d units, kernel %.4f ms; chain %zu: median %.0f max %.0f; solo %zu: median %.0f p90 %.0f max %.0f; slowest: window %d columns [%d, %d) flags %d\n",
+                    it, n, span, cd.size(), cd.empty() ? 0.0 : cd[cd.size() / 2], cd.empty() ? 0.0 : cd.back(), sd.size(), sd.empty() ? 0.0 : sd[sd.size() / 2],
+                    sd.empty() ? 0.0 : sd[sd.size() * 9 / 10], sd.empty() ? 0.0 : sd.back(), um.w, um.ia, um.ib, um.flags);
+        }
+        if (span <= 0.0) break;
+        if (it == 0) first_span = span;
+        if (!have_best || span < best_span) { best_span = span; best = h->host_units; have_best = true; uploaded_best = true; }
+        else uploaded_best = false;
+        h->tune_rounds = it + 1;
+        if (it + 1 == rounds) break;
+        std::vector<double> all;
+        for (int u = 0; u < n; u++) {
+            if (dur[u] <= 0.0) continue;
+            all.push_back(dur[u]);
+            if (h->host_units[u].flags & MU_CHAIN) chain_dur.push_back(dur[u]);
+        }
+        std::vector<double> &refv = chain_dur.size() >= 16 ? chain_dur : all;
+        if (refv.empty()) break;
+        std::nth_element(refv.begin(), refv.begin() + refv.size() / 2, refv.end());
+        const double ref = refv[refv.size() / 2];
+        for (int u = 0; u < n; u++) {
+            const MarchUnit &un = h->host_units[u];
+            if (dur[u] <= 0.0 || (un.flags & MU_CHAIN)) continue;
+            const float r = (float)pow(dur[u] / ref, damp);
+            for (int x = un.ia; x < un.ib; x++) {
+                float &c = colw[(size_t)un.w * ld + x + 1];
+                c = std::min(6.0f, std::max(0.2f, c * r));
+            }
+        }
+        MarchPlan pl;
+        cut_units(h, colw.data(), &pl);
+        if (pl.units.empty()) break;
+        WT_TRY(upload_units(h, pl));
+        uploaded_best = false;
+    }
+    if (have_best && !uploaded_best) {
+        MarchPlan pl;
+        pl.units = best;
+        pl.chunk = h->fuse_chunk_used;
+        WT_TRY(upload_units(h, pl));
+    }
+    if (best_span > 0.0) h->tune_gain = first_span / best_span;
+    return WT_OK;
+}
+
 // fp32 plans of depth 4 take three-step passes while the division by tau has to be the IEEE one (fast_div off, or a tau the proof rejects)
 static int set_tau_cap(wt_handle *h, double tau)
 {
@@ -1089,6 +1278,7 @@ static int set_tau_cap(wt_handle *h, double tau)
 static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
 {
     WT_TRY(set_tau_cap(h, tau));
+    if (!h->plan_tuned && nsteps >= 2 && h->fuse_ready) WT_TRY(tune_fuse_plan(h, tau, u0));
     int s = 0;
     while (s < nsteps) {
         const int k = fuse_stride(h, nsteps - s);
@@ -1270,6 +1460,7 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
     for (int r = 0; r < n; r++) {
         HIP_TRY(hipSetDevice(hs[r]->device));
         WT_TRY(set_tau_cap(hs[r], tau));
+        if (!hs[r]->plan_tuned && nsteps >= 2 && hs[r]->fuse_ready) WT_TRY(tune_fuse_plan(hs[r], tau, u0));
     }
     int s = 0;
     while (s < nsteps) {

@@ -26,11 +26,15 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
     const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
     // max_cost > 0 (the fuse_chunk option): the cut by owned columns; otherwise the library's default, the cut by time
     const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
-    const bool chain_timed = depth >= 3 && max_cost <= 0 && timed == 1;
-    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, 1.25, 0.6, 160};
+    const bool chain_timed = depth >= 3 && max_cost <= 0 && (timed == 1 || timed == 3);
+    // timed 3 / 4: with measured corrections of the column costs (tune_fuse_plan), here random factors within the library's clamp
+    std::vector<float> colw;
+    if (timed >= 3) { colw.resize(wcls.size()); for (float &c : colw) c = 0.2f + 5.8f * (float)(rng() % 1000) / 999.0f; }
+    const float *cw = colw.empty() ? nullptr : colw.data();
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, 1.25, 0.6, 160, 0.3};
     MarchPlan pl = (max_cost > 0 || timed == 0) ? build_march_plan(wcls.data(), g, win, target, max_cost, 2.0, &r, min_last, max_len, depth >= 3 ? 4 : 1)
-                   : chain_timed                ? build_chain_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, depth, cc)
-                                                : build_march_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, over, tail);
+                   : chain_timed                ? build_chain_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, depth, cc, cw)
+                                                : build_march_plan_timed(wcls.data(), g, win, target, 2.2, r, min_last, max_len, over, tail, 0.3, cw);
     int bad = 0;
     size_t n_chain = 0;
     if (depth >= 3) {
@@ -99,6 +103,9 @@ int main()
         bad += check("short window", 9, 300, 0, 9, win, depth, 2048, 0, 12);
         bad += check("whole lattice, by time, solo", 4096, 4096, 0, 4096, win, depth, 4096, 0, 13, 2);
         bad += check("middle slab, by time, solo", 544, 4096, 1760, 4096, win, depth, 2048, 0, 14, 2);
+        bad += check("whole lattice, measured costs", 4096, 4096, 0, 4096, win, depth, 2048, 0, 15, 3);
+        bad += check("middle slab, measured costs", 544, 4096, 1760, 4096, win, depth, 2048, 0, 16, 3);
+        bad += check("slab, measured costs, solo", 544, 4096, 1760, 4096, win, depth, 2048, 0, 17, 4);
     }
     printf("%s\n", bad ? "PLAN CHECK FAILED" : "plan check passed");
     return bad ? 1 : 0;

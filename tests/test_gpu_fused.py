@@ -350,3 +350,43 @@ def test_slabs_choose_one_plan_depth_and_mixed_groups_still_take_fused_passes(pk
             for e in es:
                 e.close()
         assert bits_equal(f0, f1), forced
+
+
+@pytest.mark.parametrize("dtype,depth", [("float32", 4), ("float32", 3), ("float64", 4)])
+def test_measured_refinement_of_the_units_changes_no_bit(pkg, oracle_c, dtype, depth):
+    """The library times the units of a new plan and cuts the columns again (tune_fuse_plan) before its first pass: the trial passes
+    must leave the populations, the step count and (rho,ux,uy) alone, and a refined plan computes the bits of the modelled one and
+    of the oracle."""
+    nx, ny, tau, u0 = 1536, 1024, 0.56, 0.07
+    mask = _body(pkg, nx, ny)
+    out = {}
+    for tune in (1, 0):
+        with pkg.Engine(nx, ny, dtype=dtype) as e:
+            e.set_option("tune", tune)
+            e.set_option("fuse_depth", depth)
+            e.set_option("fuse_steps", 2)
+            e.set_mask(mask)
+            e.init_equilibrium(u0)
+            e.step(1, tau, u0)                      # a single step: no plan is timed for it
+            assert e.get_option("tune_rounds") == 0
+            f1 = e.read_f()
+            e.step(depth, tau, u0)                  # the first pass: the plan is timed before it
+            assert (e.get_option("tune_rounds") > 0) == bool(tune)
+            assert e.get_option("tune_gain") >= 1.0 or not tune
+            assert e.info().steps_done == 1 + depth
+            e.step(2 * depth + 1, tau, u0)
+            out[tune] = (f1, e.read_f(), e.read_macro(), e.get_option("fuse_units"))
+            # a new mask is timed again, and turning the option off brings the modelled cut back
+            e.set_mask(_body(pkg, nx, ny, aoa=3.0))
+            e.step(depth, tau, u0)
+            assert (e.get_option("tune_rounds") > 0) == bool(tune)
+            e.set_option("tune", 0)
+            e.step(depth, tau, u0)
+            assert e.get_option("tune_rounds") == 0
+    assert bits_equal(out[1][0], out[0][0]) and bits_equal(out[1][1], out[0][1])
+    for a, b in zip(out[1][2], out[0][2]):
+        assert bits_equal(a, b)
+    fr, mr = oracle_c.run(mask, 1 + depth + 2 * depth + 1, tau, u0, np.dtype(dtype))
+    assert bits_equal(out[1][1], fr)
+    for a, b in zip(out[1][2], mr):
+        assert bits_equal(a, b)
