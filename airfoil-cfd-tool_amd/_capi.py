@@ -21,7 +21,7 @@ WT_FIELD_SPEED, WT_FIELD_CP, WT_FIELD_VORT = 0, 1, 2
 WT_COMM_ID_BYTES = 128
 
 EXPORTS = (
-    "wt_create", "wt_create_slab", "wt_destroy", "wt_get_info", "wt_last_error", "wt_version",
+    "wt_create", "wt_create_slab", "wt_create_slab_at", "wt_destroy", "wt_get_info", "wt_last_error", "wt_version",
     "wt_set_option", "wt_get_option",
     "wt_comm_unique_id", "wt_comm_init_rank", "wt_comm_selftest", "wt_link_local", "wt_step_group", "wt_step_group_timed",
     "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_plan_steps", "wt_read_f", "wt_write_f",
@@ -67,6 +67,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     sig = {
         "wt_create": ([c_int, c_int, c_int, c_int, POINTER(H)], c_int),
         "wt_create_slab": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(H)], c_int),
+        "wt_create_slab_at": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(H)], c_int),
         "wt_destroy": ([H], c_int),
         "wt_get_info": ([H, POINTER(WtInfo)], c_int),
         "wt_last_error": ([], c_char_p),
@@ -120,15 +121,21 @@ class Engine:
     """One libwindtunnel handle (a whole lattice, or one column slab of it)."""
 
     def __init__(self, nx: int, ny: int, dtype="float32", device: int = 0,
-                 rank: int = 0, nranks: int = 1, halo: int = 0):
+                 rank: int = 0, nranks: int = 1, halo: int = 0, edges=None):
+        """edges: the split of a slab tunnel, nranks + 1 rising column indices from 0 to nx (None: equal widths)."""
         self._lib = load_library()
         self.dtype = _np_dtype(dtype)
         self._h = c_void_p()
         code = WT_F32 if self.dtype == np.float32 else WT_F64
         if nranks == 1:
             _check(self._lib.wt_create(nx, ny, code, device, byref(self._h)))
-        else:
+        elif edges is None:
             _check(self._lib.wt_create_slab(nx, ny, code, device, rank, nranks, halo, byref(self._h)))
+        else:
+            if len(edges) != nranks + 1:
+                raise ValueError(f"edges must hold nranks + 1 = {nranks + 1} column indices")
+            arr = (c_int * (nranks + 1))(*[int(e) for e in edges])
+            _check(self._lib.wt_create_slab_at(nx, ny, code, device, rank, nranks, halo, arr, byref(self._h)))
         info = self.info()
         self.nx_global, self.ny = info.nx_global, info.ny
         self.x0, self.width = info.x0, info.width

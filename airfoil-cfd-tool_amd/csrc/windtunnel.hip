@@ -73,6 +73,7 @@ struct wt_handle {
     int nx_g = 0, ny = 0, dtype = WT_F32, device = 0;
     int rank = 0, nranks = 1, halo = 0;
     int x0 = 0, width = 0;       // owned global columns [x0, x0+width)
+    int min_width = 0;           // owned columns of the narrowest slab of the tunnel
     int gl = 0, gr = 0;          // ghost columns on the left / right
     Geom g{};                    // local geometry
     size_t esz = 4;              // element size
@@ -169,7 +170,7 @@ static int check_handle(const wt_handle *h)
 // ------------------------------------------------------------------------------------------
 // life cycle
 // ------------------------------------------------------------------------------------------
-static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nranks, int halo, wt_handle **out)
+static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nranks, int halo, const int *edges, wt_handle **out)
 {
     if (!out) return fail(WT_ERR_ARG, "out is null");
     *out = nullptr;
@@ -191,11 +192,19 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     if (!h) return fail(WT_ERR_OOM, "host allocation failed");
     h->nx_g = nx_g; h->ny = ny; h->dtype = dtype; h->device = device;
     h->rank = rank; h->nranks = nranks;
-    h->x0 = (int)((long long)rank * nx_g / nranks);
-    const int x1 = (int)((long long)(rank + 1) * nx_g / nranks);
-    h->width = x1 - h->x0;
-    if (nranks > 1 && h->width < 2) { delete h; return fail(WT_ERR_ARG, "slab narrower than 2 columns"); }
-    if (nranks > 1 && halo > h->width) { delete h; return fail(WT_ERR_ARG, "halo %d wider than the slab (%d columns)", halo, h->width); }
+    // the split: the caller's (wt_create_slab_at) or equal widths; the narrowest slab of all decides the plan depth of every rank
+    h->min_width = nx_g;
+    for (int r = 0; r < nranks; r++) {
+        const int a = edges ? edges[r] : (int)((long long)r * nx_g / nranks), b = edges ? edges[r + 1] : (int)((long long)(r + 1) * nx_g / nranks);
+        if (edges && (a < 0 || b > nx_g || b <= a || (r == 0 && a != 0) || (r == nranks - 1 && b != nx_g))) {
+            delete h;
+            return fail(WT_ERR_ARG, "edges must rise from 0 to nx_global (slab %d: [%d, %d))", r, a, b);
+        }
+        if (b - a < h->min_width) h->min_width = b - a;
+        if (r == rank) { h->x0 = a; h->width = b - a; }
+    }
+    if (nranks > 1 && halo > h->min_width) { delete h; return fail(WT_ERR_ARG, "halo %d wider than the narrowest slab (%d columns)", halo, h->min_width); }
+    if (nranks > 1 && h->min_width < 2) { delete h; return fail(WT_ERR_ARG, "slab narrower than 2 columns"); }
     h->halo = nranks > 1 ? halo : 0;
     h->gl = (rank > 0) ? h->halo : 0;
     h->gr = (rank < nranks - 1) ? h->halo : 0;
@@ -274,13 +283,21 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
 
 extern "C" int wt_create(int nx, int ny, int dtype, int device, wt_handle **out)
 {
-    return create_impl(nx, ny, dtype, device, 0, 1, 0, out);
+    return create_impl(nx, ny, dtype, device, 0, 1, 0, nullptr, out);
 }
 
 extern "C" int wt_create_slab(int nx_global, int ny, int dtype, int device, int rank, int nranks, int halo,
                               wt_handle **out)
 {
-    return create_impl(nx_global, ny, dtype, device, rank, nranks, halo, out);
+    return create_impl(nx_global, ny, dtype, device, rank, nranks, halo, nullptr, out);
+}
+
+extern "C" int wt_create_slab_at(int nx_global, int ny, int dtype, int device, int rank, int nranks, int halo, const int *edges,
+                                 wt_handle **out)
+{
+    if (!edges) return fail(WT_ERR_ARG, "edges is null");
+    if (nranks < 1) return fail(WT_ERR_ARG, "bad rank %d of %d", rank, nranks);
+    return create_impl(nx_global, ny, dtype, device, rank, nranks, halo, edges, out);
 }
 
 extern "C" int wt_destroy(wt_handle *h)
@@ -545,8 +562,8 @@ static int rebuild_fuse_plan(wt_handle *h)
     const bool two_on_three = h->dtype != WT_F32 && h->fuse_depth == 2;  // fp64: two-step passes on the three-step tables
     // Every slab of a tunnel must take the SAME sequence of passes and refresh steps (the exchange is collective: over RCCL each rank
     // decides on its own), so the automatic choices below look at the NARROWEST slab of the split — an edge slab, W + halo columns —
-    // whatever this slab's own width is: a quantity every rank computes alike from (nx_global, nranks, halo).
-    const int plan_nxl = h->nranks > 1 ? h->nx_g / h->nranks + h->halo : h->g.nxl;
+    // whatever this slab's own width is: a quantity every rank computes alike from the split and the halo depth.
+    const int plan_nxl = h->nranks > 1 ? h->min_width + h->halo : h->g.nxl;
     const bool depth3_ok = std::min(h->g.nxl, plan_nxl) >= 16 && (h->fuse_depth != 2 || two_on_three);
     if (depth3_ok) {
         // Steps per pass (round 3, tools/run_width_sweep.sh, us per step on 4096 rows, fp32, steps per pass 2 / 3 / 4): 288 columns 16.5 / 17.7 /

@@ -20,15 +20,85 @@ import numpy as np
 from .windtunnel import FIELD_MODES, VORT_SCALE, WindTunnel
 
 
-def slab_bounds(nx: int, nranks: int) -> List[Tuple[int, int]]:
-    """(x0, width) of every slab — the same split wt_create_slab makes: [r*NX/P, (r+1)*NX/P)."""
-    edges = [r * nx // nranks for r in range(nranks + 1)]
+def slab_edges(nx: int, nranks: int) -> List[int]:
+    """Equal widths — the split wt_create_slab makes: slab r owns [r*NX/P, (r+1)*NX/P)."""
+    return [r * nx // nranks for r in range(nranks + 1)]
+
+
+def slab_bounds(nx: int, nranks: int, edges: Optional[List[int]] = None) -> List[Tuple[int, int]]:
+    """(x0, width) of every slab of a split (equal widths unless `edges` is given)."""
+    edges = slab_edges(nx, nranks) if edges is None else [int(e) for e in edges]
     return [(edges[r], edges[r + 1] - edges[r]) for r in range(nranks)]
 
 
-def _default_engine_factory(nx, ny, dtype, device, rank, nranks, halo):
+def balanced_edges(edges: List[int], cost: List[float], min_width: int) -> List[int]:
+    """One round of cutting the slabs by cost instead of by width.  `cost[r]` is what slab r of the split `edges` was measured to take per
+    step (any unit): the cost is spread evenly over the slab's columns, and the new edges cut the running cost into equal parts.
+    Slabs that hold the body come out narrower, plain ones wider; no slab gets fewer than `min_width` columns (>= the halo depth).
+    A slab's cost is not linear in its columns (fixed costs per pass, body columns inside), so the caller repeats: measure the new split,
+    cut again (bench.py --balance; two or three rounds settle within a few percent)."""
+    P = len(edges) - 1
+    if P < 2:
+        return list(edges)
+    dens = [float(cost[r]) / max(1, edges[r + 1] - edges[r]) for r in range(P)]
+    total = sum(dens[r] * (edges[r + 1] - edges[r]) for r in range(P))
+    new = [edges[0]]
+    r, acc = 0, 0.0                       # acc: cost of the columns left of edges[r]
+    for k in range(1, P):
+        want = total * k / P
+        while r < P - 1 and acc + dens[r] * (edges[r + 1] - edges[r]) < want:
+            acc += dens[r] * (edges[r + 1] - edges[r])
+            r += 1
+        x = edges[r] + (want - acc) / dens[r] if dens[r] > 0 else edges[r + 1]
+        new.append(int(round(x)))
+    new.append(edges[-1])
+    for k in range(1, P):                 # minimum widths, left to right, then right to left
+        new[k] = max(new[k], new[k - 1] + min_width)
+    for k in range(P - 1, 0, -1):
+        new[k] = min(new[k], new[k + 1] - min_width)
+    if any(new[k + 1] - new[k] < min_width for k in range(P)):
+        raise ValueError(f"{P} slabs of at least {min_width} columns do not fit {edges[-1] - edges[0]} columns")
+    return new
+
+
+def measure_slab_cost(mask: np.ndarray, edges: List[int], rank: int, halo: int, dtype="float32", device: int = 0, tau: float = 0.58,
+                      u0: float = 0.06, steps: int = 200, options=None) -> float:
+    """Microseconds per step of slab `rank` of the split on its own: a stand-alone handle of the slab's owned + ghost columns on the mask
+    columns it would hold (its cut edges act as inlet / outlet, which costs a little more than the ghost columns of the real slab).
+    No neighbour and no communicator is involved, so the ranks of a process group measure their candidate slabs side by side."""
     from ._capi import Engine
-    return Engine(nx, ny, dtype=dtype, device=device, rank=rank, nranks=nranks, halo=halo)
+    nx = mask.shape[1]
+    lo, hi = max(0, edges[rank] - halo), min(nx, edges[rank + 1] + halo)
+    with Engine(hi - lo, mask.shape[0], dtype=dtype, device=device) as e:
+        for k, v in (options or {}).items():
+            e.set_option(k, v)
+        e.set_mask(np.ascontiguousarray(mask[:, lo:hi]))
+        e.init_equilibrium(u0)
+        e.step(24, tau, u0)
+        return e.step_timed(steps, tau, u0) / steps * 1e3
+
+
+def balance_split(nx: int, nranks: int, min_width: int, measure: Callable[[List[int]], List[float]], rounds: int = 3):
+    """Equal widths first, then `rounds` times: measure every slab of the split (`measure(edges)` -> cost per slab, the same list on every
+    caller), cut by cost (balanced_edges).  Returns (edges of the split whose SLOWEST slab was fastest, history of (edges, costs))."""
+    edges = slab_edges(nx, nranks)
+    history = []
+    for _ in range(max(0, rounds) + 1):
+        cost = [float(c) for c in measure(edges)]
+        history.append((list(edges), cost))
+        if len(history) > rounds:
+            break
+        nxt = balanced_edges(edges, cost, min_width)
+        if nxt == edges:
+            break
+        edges = nxt
+    best = min(history, key=lambda h: max(h[1]))
+    return best[0], history
+
+
+def _default_engine_factory(nx, ny, dtype, device, rank, nranks, halo, edges=None):
+    from ._capi import Engine
+    return Engine(nx, ny, dtype=dtype, device=device, rank=rank, nranks=nranks, halo=halo, edges=edges)
 
 
 class SlabWindTunnel(WindTunnel):
@@ -36,7 +106,9 @@ class SlabWindTunnel(WindTunnel):
     Every method is collective: all ranks call it with the same arguments."""
 
     def __init__(self, coords=None, name: str = "", *, halo: int = 16, device: Optional[int] = None, group=None,
-                 engine_factory: Callable = _default_engine_factory, nx: int = 4096, ny: int = 2048, **kwargs):
+                 engine_factory: Callable = _default_engine_factory, nx: int = 4096, ny: int = 2048, edges: Optional[List[int]] = None,
+                 **kwargs):
+        """edges: the split (nranks + 1 rising column indices, the same on every rank; see balanced_edges), None for equal widths."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("SlabWindTunnel needs an initialised torch.distributed process group")
@@ -44,7 +116,8 @@ class SlabWindTunnel(WindTunnel):
         self.group = group
         self.rank = dist.get_rank(group)
         self.nranks = dist.get_world_size(group)
-        self.bounds = slab_bounds(int(nx), self.nranks)
+        self.edges = None if edges is None else [int(e) for e in edges]
+        self.bounds = slab_bounds(int(nx), self.nranks, self.edges)
         self.x0, self.width = self.bounds[self.rank]
         self.halo = int(halo) if self.nranks > 1 else 0
         self._engine_factory = engine_factory
@@ -60,7 +133,10 @@ class SlabWindTunnel(WindTunnel):
 
     # ---- hooks -------------------------------------------------------------------------
     def _make_engine(self, dtype, device):
-        eng = self._engine_factory(self.nx, self.ny, dtype, device, self.rank, self.nranks, self.halo)
+        if self.edges is None:
+            eng = self._engine_factory(self.nx, self.ny, dtype, device, self.rank, self.nranks, self.halo)
+        else:
+            eng = self._engine_factory(self.nx, self.ny, dtype, device, self.rank, self.nranks, self.halo, edges=self.edges)
         if (eng.x0, eng.width) != (self.x0, self.width):
             raise RuntimeError("engine and host disagree on the slab bounds")
         if self.nranks > 1:
@@ -147,11 +223,11 @@ class _LocalSlabEngine:
     """Engine-shaped facade over P locally linked slab handles (one process, any mix of devices):
     ghost columns move by peer copies (wt_link_local), all slabs advance in lock-step (wt_step_group)."""
 
-    def __init__(self, nx, ny, dtype, devices, halo):
+    def __init__(self, nx, ny, dtype, devices, halo, edges=None):
         from ._capi import Engine
         self._Engine = Engine
         P = len(devices)
-        self.slabs = [Engine(nx, ny, dtype=dtype, device=d, rank=r, nranks=P, halo=halo) for r, d in enumerate(devices)]
+        self.slabs = [Engine(nx, ny, dtype=dtype, device=d, rank=r, nranks=P, halo=halo, edges=edges) for r, d in enumerate(devices)]
         Engine.link_local(self.slabs)
         self.dtype = self.slabs[0].dtype
         self.nx_global, self.ny, self.x0, self.width = nx, ny, 0, nx
@@ -208,12 +284,13 @@ class LocalSlabWindTunnel(WindTunnel):
     """:class:`WindTunnel` over several GPUs driven by ONE process (no torch.distributed, no RCCL):
     ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=16, nx=8192, ny=4096)``."""
 
-    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: int = 16, **kwargs):
+    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: int = 16, edges=None, **kwargs):
         self.devices = [int(d) for d in devices]
         self.halo = int(halo)
+        self.edges = None if edges is None else [int(e) for e in edges]
         if len(self.devices) < 2:
             raise ValueError("LocalSlabWindTunnel needs at least two slabs; use WindTunnel for one GPU")
         super().__init__(coords, name, device=self.devices[0], **kwargs)
 
     def _make_engine(self, dtype, device):
-        return _LocalSlabEngine(self.nx, self.ny, dtype, self.devices, self.halo)
+        return _LocalSlabEngine(self.nx, self.ny, dtype, self.devices, self.halo, self.edges)

@@ -84,6 +84,10 @@ def parse_args():
                     help="1 (default, one GPU only): before the timed run, measure this workload's HBM traffic per launch in this session — two short "
                          "child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` — and use it for roofline.traffic / frac; "
                          "0, or when rocprofv3 is not available: the entry of profiles/pmc_traffic.json (measured in another run), if there is one")
+    ap.add_argument("--balance", type=int, default=-1, metavar="R",
+                    help="slab runs with strong scaling: R rounds of cutting the slabs by MEASURED cost instead of equal widths before the run (every rank "
+                         "times its candidate slab alone, airfoil_cfd_tool_amd.distributed.balance_split; the split with the fastest slowest slab is kept, "
+                         "the equal one included).  -1 (default): 3 rounds when there is more than one slab, 0: equal widths")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -263,6 +267,26 @@ def workload_name(args, nx_total, ny, body_name):
     return f"{body_name} {nx_total}x{ny} {args.dtype} D2Q9, AoA={args.aoa:g} deg, U0={args.u0:g}, tau={args.tau:g} ({note})"
 
 
+def slab_options(args):
+    """The marching options of this run, for the stand-alone handles that measure a candidate slab."""
+    o = {}
+    if args.fuse_chunk > 0:
+        o["fuse_chunk"] = args.fuse_chunk
+    if args.fuse_depth > 0:
+        o["fuse_depth"] = args.fuse_depth
+    if args.fuse >= 0:
+        o["fuse_steps"] = args.fuse
+    if args.fast_math == 1:
+        o["fast_math"] = 1
+    return o
+
+
+def balance_report(history):
+    """[(edges, per-slab us/step)] of every split tried -> JSON-able summary."""
+    return [{"widths": [b - a for a, b in zip(ed[:-1], ed[1:])], "slab_us_per_step": [round(c, 2) for c in cost], "slowest": round(max(cost), 2)}
+            for ed, cost in history]
+
+
 def local_slabs_main(args, wtpkg, mask, body_name):
     """--local-slabs P: the column-slab path of `--gpus P` with every slab on device 0 (in-process transport: peer copies on each
     slab's comm stream in place of RCCL send/recv; every other line of the slab state machine is shared, csrc/windtunnel.hip
@@ -271,7 +295,13 @@ def local_slabs_main(args, wtpkg, mask, body_name):
     import torch
     P, ny, nx = args.local_slabs, args.ny, args.nx
     torch.cuda.set_device(0)
-    es = [wtpkg.Engine(nx, ny, dtype=args.dtype, device=0, rank=r, nranks=P, halo=args.halo) for r in range(P)]
+    edges, history = None, []
+    rounds = 3 if args.balance < 0 else args.balance
+    if P > 1 and rounds > 0:
+        opts = slab_options(args)
+        edges, history = wtpkg.balance_split(nx, P, max(args.halo, 32), lambda ed: [
+            wtpkg.measure_slab_cost(mask, ed, r, args.halo, dtype=args.dtype, device=0, tau=args.tau, u0=args.u0, options=opts) for r in range(P)], rounds)
+    es = [wtpkg.Engine(nx, ny, dtype=args.dtype, device=0, rank=r, nranks=P, halo=args.halo, edges=edges) for r in range(P)]
     try:
         wtpkg.Engine.link_local(es)
         for e in es:
@@ -310,7 +340,8 @@ def local_slabs_main(args, wtpkg, mask, body_name):
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "float32" else "f64", "data": "synthetic",
             "config": {"workload": workload_name(args, nx, ny, body_name) + f" as {P} LOCAL column slabs on one GPU", "nx": nx, "ny": ny,
-                       "slabs": P, "halo": args.halo, "transport": "local (hipMemcpyPeerAsync on each slab's comm stream)",
+                       "slabs": P, "halo": args.halo, "transport": "local (copy kernel on each slab's comm stream)",
+                       "edges": [e.x0 for e in es] + [nx], "balance": balance_report(history),
                        "fuse_depth": [int(e.get_option("fuse_depth")) if e.get_option("fuse_active") else 0 for e in es],
                        "single_steps": [int(e.get_option("single_steps")) for e in es]},
             "local_slabs": {"device_ms_per_step": [m / args.steps for m in dev_ms], "sum_device_ms_per_step": sum(dev_ms) / args.steps,
@@ -382,9 +413,35 @@ def main():
     if args.local_slabs > 0:
         return local_slabs_main(args, wtpkg, mask, body_name)
 
+    edges, balance_hist = None, []
+    rounds = (3 if args.balance < 0 else args.balance) if (distributed and args.scaling == "strong") else 0
+    if rounds > 0:
+        # every rank times ITS slab of the candidate split alone on its GPU (no communicator involved), the costs are gathered, the
+        # columns are cut again; a failure anywhere leaves every rank on equal widths
+        def measure(ed):
+            ok, mine = 1.0, 0.0
+            try:
+                mine = wtpkg.measure_slab_cost(mask, ed, rank, args.halo, dtype=args.dtype, device=local_rank, tau=args.tau, u0=args.u0,
+                                               options=slab_options(args))
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench rank {rank}] slab measurement failed: {e}", file=sys.stderr, flush=True)
+                ok = 0.0
+            t = torch.tensor([mine, ok], dtype=torch.float64, device="cuda")
+            got = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(got, t)
+            if min(float(g[1]) for g in got) < 1.0:
+                raise RuntimeError("a rank could not measure its slab")
+            return [float(g[0]) for g in got]
+        try:
+            edges, balance_hist = wtpkg.balance_split(nx_total, world, max(args.halo, 32), measure, rounds)
+        except Exception as e:      # noqa: BLE001 - the same exception on every rank (the flag above is gathered)
+            if rank == 0:
+                print(f"[bench] slab balancing skipped: {e}", file=sys.stderr, flush=True)
+            edges, balance_hist = None, []
+
     try:
         if distributed:
-            eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank, rank=rank, nranks=world, halo=args.halo)
+            eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank, rank=rank, nranks=world, halo=args.halo, edges=edges)
         else:
             eng = wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank)
         if args.fuse_chunk > 0:
@@ -447,7 +504,7 @@ def main():
     # one launch = one pass of the dominant kernel over the slab (when --steps is not a multiple of the steps per pass the
     # last one or two steps are single steps; they are averaged in)
     launch_ms = dev_ms / args.steps * steps_per_launch
-    sites_per_launch = eng.width * ny if not distributed else (nx_total // world) * ny
+    sites_per_launch = eng.width * ny
     key = f"{nx_total}x{ny}_{args.dtype}"
     main_kernel = "wt::k_step"
     if fused and steps_per_launch == 4:
@@ -529,7 +586,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload, "nx": nx_total, "ny": ny, "slabs": world,
                    "halo": args.halo if distributed else 0, **cfg_fuse, "fast_math": int(args.fast_math == 1),
-                   "solid_sites": int((mask != 0).sum())},
+                   "solid_sites": int((mask != 0).sum()),
+                   **({"slab_widths": [w for _, w in wtpkg.slab_bounds(nx_total, world, edges)], "balance": balance_report(balance_hist)} if distributed else {})},
         "device_ms": per_rank_ms,
         "roofline": roofline,
     }

@@ -77,6 +77,14 @@ int wt_create(int nx, int ny, int dtype, int device, wt_handle **out);
 int wt_create_slab(int nx_global, int ny, int dtype, int device,
                    int rank, int nranks, int halo, wt_handle **out);
 
+/* The same with the split given by the caller: edges[0] = 0 < edges[1] < ... <
+ * edges[nranks] = nx_global, rank r owns [edges[r], edges[r+1]).  Every rank
+ * passes the SAME array (the narrowest slab decides the steps per pass of all
+ * of them).  For tunnels whose body makes some columns dearer than others:
+ * the host cuts the slabs by measured cost (distributed.balanced_edges). */
+int wt_create_slab_at(int nx_global, int ny, int dtype, int device,
+                      int rank, int nranks, int halo, const int *edges, wt_handle **out);
+
 int wt_destroy(wt_handle *h);
 int wt_get_info(const wt_handle *h, wt_info *info);
 const char *wt_last_error(void);

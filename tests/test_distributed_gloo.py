@@ -7,6 +7,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,3 +45,31 @@ def test_slab_bounds(pkg):
     assert slab_bounds(10, 3) == [(0, 3), (3, 3), (6, 4)]
     b = slab_bounds(16384, 8)
     assert b[0] == (0, 2048) and b[-1] == (14336, 2048)
+
+
+def test_slabs_cut_by_cost(pkg):
+    """distributed.balanced_edges / balance_split: host logic of the split by measured cost (no GPU: the 'measurement' is a model)."""
+    from airfoil_cfd_tool_amd.distributed import balance_split, balanced_edges, slab_bounds, slab_edges
+    assert slab_edges(4096, 8) == [512 * r for r in range(9)]
+    assert slab_bounds(100, 3, [0, 10, 50, 100]) == [(0, 10), (10, 40), (50, 50)]
+    assert balanced_edges([0, 10, 20], [1.0, 1.0], 3) == [0, 10, 20]
+    e = balanced_edges([0, 10, 20], [1.0, 3.0], 3)
+    assert e[0] == 0 and e[2] == 20 and 10 < e[1] <= 17                     # the dear slab gets narrower
+    assert balanced_edges([0, 10, 20], [0.0, 3.0], 8) == [0, 12, 20]         # minimum width kept
+    with pytest.raises(ValueError):
+        balanced_edges([0, 10, 20], [1.0, 1.0], 11)
+
+    # a tunnel whose columns 1000..3000 cost 2.5 x the plain ones, plus a fixed cost per slab
+    dens = np.ones(4096); dens[1000:3000] = 2.5
+
+    def measure(edges):
+        return [5.0 + 0.02 * dens[a:b].sum() for a, b in zip(edges[:-1], edges[1:])]
+    best, hist = balance_split(4096, 8, 32, measure, rounds=4)
+    assert best[0] == 0 and best[-1] == 4096 and all(b - a >= 32 for a, b in zip(best[:-1], best[1:]))
+    assert hist[0][0] == slab_edges(4096, 8)
+    first, kept = max(hist[0][1]), max(measure(best))
+    ideal = 5.0 + 0.02 * dens.sum() / 8
+    assert kept < first and kept < 1.03 * ideal                             # equal widths: 30.6, ideal 22.7
+    # a split that cannot be improved stays
+    best2, hist2 = balance_split(4096, 8, 32, lambda ed: [1.0] * 8, rounds=3)
+    assert best2 == slab_edges(4096, 8) and len(hist2) == 1

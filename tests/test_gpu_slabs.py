@@ -19,10 +19,12 @@ def _single(pkg, mask, chunks, tau, u0, dtype):
         return e.read_f(), e.read_macro(), e.reduce_ranges(u0), e.forces()
 
 
-def _slabs(pkg, mask, nranks, halo, chunks, tau, u0, dtype):
+def _slabs(pkg, mask, nranks, halo, chunks, tau, u0, dtype, edges=None):
     ny, nx = mask.shape
-    es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=nranks, halo=halo, edges=edges) for r in range(nranks)]
     try:
+        if edges is not None:
+            assert [e.x0 for e in es] == list(edges[:-1]) and [e.width for e in es] == [b - a for a, b in zip(edges[:-1], edges[1:])]
         assert sum(e.width for e in es) == nx and es[0].x0 == 0
         pkg.Engine.link_local(es)
         for e in es:
@@ -59,6 +61,45 @@ def test_slabs_equal_single_lattice(pkg, nranks, halo, nx, ny, dtype):
     assert r0 == r1
     assert F0[2:] == F1[2:]
     np.testing.assert_allclose(F0[:2], F1[:2], rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("edges,halo,nx,ny,dtype,fuse", [
+    ([0, 100, 130, 400, 512], 3, 512, 256, "float32", 0),
+    ([0, 700, 1100, 1500, 2048], 16, 2048, 1024, "float32", 2),       # marching passes; the widest slab alone would plan deeper than the group does
+    ([0, 300, 330, 1024], 8, 1024, 512, "float64", 2),
+    ([0, 40, 2048], 16, 2048, 1024, "float32", 2),
+])
+def test_slabs_cut_by_the_caller_equal_single_lattice(pkg, edges, halo, nx, ny, dtype, fuse):
+    """wt_create_slab_at: slabs of unequal widths (the host cuts them by measured cost, distributed.balance_split).  Same bits as the
+    whole lattice; every slab takes the schedule the narrowest one allows."""
+    mask = pkg.geometry.build_geometry(nx, ny, 7.0, None, "naca2412").mask
+    chunks = [1, 2, halo, 2 * halo + 1, 23]
+    f0, m0, r0, F0 = _single(pkg, mask, chunks, 0.58, 0.06, dtype)
+    f1, m1, r1, F1 = _slabs(pkg, mask, len(edges) - 1, halo, chunks, 0.58, 0.06, dtype, edges=edges)
+    assert bits_equal(f0, f1)
+    assert all(bits_equal(a, b) for a, b in zip(m0, m1))
+    assert r0 == r1 and F0[2:] == F1[2:]
+    if fuse:
+        es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=len(edges) - 1, halo=halo, edges=edges) for r in range(len(edges) - 1)]
+        try:
+            for e in es:
+                e.set_mask(mask); e.init_equilibrium(0.06)
+            plans = [tuple(e.plan_steps(41, 0.58)) for e in es]
+            assert len(set(plans)) == 1, plans
+            assert len({(e.get_option("fuse_active"), e.get_option("fuse_depth")) for e in es}) == 1
+        finally:
+            for e in es:
+                e.close()
+
+
+def test_slab_split_errors(pkg):
+    for bad in ([0, 10, 10, 64], [1, 32, 64], [0, 32, 60], [0, 40, 30, 64]):
+        with pytest.raises(pkg.WTError):
+            pkg.Engine(64, 64, rank=0, nranks=len(bad) - 1, halo=1, edges=bad)
+    with pytest.raises(pkg.WTError):
+        pkg.Engine(64, 64, rank=0, nranks=2, halo=8, edges=[0, 60, 64])        # halo wider than the narrowest slab
+    with pytest.raises(ValueError):
+        pkg.Engine(64, 64, rank=0, nranks=2, halo=1, edges=[0, 64])
 
 
 def test_slab_restart_from_written_state(pkg):
