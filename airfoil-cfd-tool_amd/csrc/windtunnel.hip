@@ -74,6 +74,7 @@ struct wt_handle {
     int rank = 0, nranks = 1, halo = 0;
     int x0 = 0, width = 0;       // owned global columns [x0, x0+width)
     int min_width = 0;           // owned columns of the narrowest slab of the tunnel
+    int plan_columns = 0;        // option "plan_columns": choose the steps per pass as for a lattice of this many local columns (0: this one's)
     int gl = 0, gr = 0;          // ghost columns on the left / right
     Geom g{};                    // local geometry
     size_t esz = 4;              // element size
@@ -563,25 +564,44 @@ static int rebuild_fuse_plan(wt_handle *h)
     // Every slab of a tunnel must take the SAME sequence of passes and refresh steps (the exchange is collective: over RCCL each rank
     // decides on its own), so the automatic choices below look at the NARROWEST slab of the split — an edge slab, W + halo columns —
     // whatever this slab's own width is: a quantity every rank computes alike from the split and the halo depth.
-    const int plan_nxl = h->nranks > 1 ? h->min_width + h->halo : h->g.nxl;
+    const int plan_nxl = h->plan_columns > 0 ? h->plan_columns : (h->nranks > 1 ? h->min_width + h->halo : h->g.nxl);
     const bool depth3_ok = std::min(h->g.nxl, plan_nxl) >= 16 && (h->fuse_depth != 2 || two_on_three);
     if (depth3_ok) {
-        // Steps per pass (round 3, tools/run_width_sweep.sh, us per step on 4096 rows, fp32, steps per pass 2 / 3 / 4): 288 columns 16.5 / 17.7 /
-        // 18.9; 416: 20.9 / 21.3 / 22.1; 544: 25.0 / 24.7 / 24.4; 800: 33.5 / 30.1 / 28.3; 1056: 41.4 / 36.8 / 33.5; 2080: - / 65.1 / 59.8; 4096: - /
-        // 114.3 / 96.7 — four steps per pass from eight columns per resident unit up, two below (the two-step kernel further down);
-        // fp64 (tools/r3_f64_sweep.sh, three / four steps per pass): 288 columns 24.5 / 24.2, 544: 36.9 / 36.4, 1056: 63.8 / 60.0, 2080: 115.9 / 107.6, 4096: 236.6 / 212.3 - four from 12 columns per unit up.
+        // Steps per pass by columns per resident unit (tools/r3_depth_at_widths.py on the kernels of round 3 — chain blocks, units cut by measured
+        // time; 4096 rows, us per step as single steps / two / three / four per pass, a plain slab | a slab over the thick part of the body):
+        //   fp32  64 columns (0 per unit)   9.8 /  9.8 /  8.8 /  9.8 | 10.3 / 10.3 / 10.4 / 12.4
+        //        100 (1)                   13.2 / 13.2 /  9.3 / 10.1 | 13.2 / 13.2 / 12.2 / 14.8
+        //        200 (3)                   14.3 / 14.2 / 10.2 / 10.4 | 15.9 / 16.0 / 13.3 / 15.8
+        //        300 (4)                   18.9 / 14.5 / 12.2 / 11.6 | 20.8 / 17.3 / 14.8 / 16.5
+        //        340 (5)                   21.5 / 15.5 / 13.2 / 11.7 | 23.5 / 18.1 / 16.3 / 17.0
+        //        420 (6)                   24.6 / 17.6 / 14.7 / 13.2 | 26.6 / 20.9 / 18.8 / 18.7
+        //        500 (7)                   29.1 / 19.9 / 16.2 / 14.5 | 31.1 / 23.8 / 20.3 / 21.4      (544 and up: run_width_sweep.sh, four)
+        //   fp64  64 (1)                   12.6 / 10.9 /  9.6 / 10.9 | 12.6 / 15.2 / 14.3 / 15.5
+        //        150 (4)                   18.3 / 15.8 / 12.5 / 13.7 | 18.7 / 19.3 / 16.6 / 17.7
+        //        300 (9)                   30.8 / 26.6 / 19.1 / 19.4 | 31.1 / 31.3 / 22.7 / 23.8
+        //        400 (12)                  39.9 / 34.9 / 24.1 / 23.0 | 41.1 / 37.8 / 27.7 / 26.7
+        // Whole tunnels with their body inside (tools/r3_small_lattices.py: 2048x1024, 7 per unit: 32.3 / - / 21.7 / 23.5; 1024x1024, 3 per unit:
+        // 18.5 / - / 15.3 / 17.1; 1024x512, 1 per unit: 13.6 / - / 13.4 / 16.1; 512x256, 0 per unit: 9.9 / - / 11.1 / 13.5) follow the body columns.
+        // fp32: three steps per pass from one column per unit up, four from eight — from five for the slabs of a split, which are mostly plain
+        // and are cut by cost (the widest, plain ones set the pace); fp64: four from 12, three from four; single steps below.
+        // (Round 2's rule — two steps per pass below eight columns per unit — predates the chain blocks: the two-step kernel is never the
+        // best choice any more and runs only when fuse_depth = 2 asks for it.)
         const long tiles3 = (long)(plan_nxl - 4) * march_nwin(h->g.ny, 64 * s3);
         const bool f32 = h->dtype == WT_F32;
-        if (f32 && h->fuse_depth == 0 && !h->fuse_force && h->fuse_chunk <= 0 && tiles3 / slots < 8) goto two_step;
-        int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && tiles3 / slots >= (f32 ? 8 : 12)) ? 4 : 3;
+        const long cpu = tiles3 / slots;
+        static const long min4_env = getenv("WT_DEPTH4_MIN") ? atol(getenv("WT_DEPTH4_MIN")) : 0;      // experiments
+        const long min4 = min4_env > 0 ? min4_env : ((h->nranks > 1 || h->plan_columns > 0) ? 5 : 8);
+        static const long min3 = getenv("WT_DEPTH3_MIN") ? atol(getenv("WT_DEPTH3_MIN")) : 1;
+        const bool force = h->fuse_force || h->fuse_depth >= 2;
+        if (!force && h->fuse_chunk <= 0 && cpu < (f32 ? min3 : 4)) return WT_OK;
+        int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && cpu >= (f32 ? min4 : 12)) ? 4 : 3;
         // The units of a depth-D plan leave the D-1 columns next to a local slab edge unwritten: those must all be GHOST columns, so a slab
         // with fewer than D-1 of them plans shallower (halo 2: three steps per pass at most; halo 1: the two-step kernel, whose units leave one).
         if (h->nranks > 1 && h->halo < depth - 1) depth = h->halo + 1;
         if (depth < 3) { if (f32) goto two_step; return WT_OK; }
         const MarchRange r = march_range3(h->g, depth);
         const long tiles = (long)(r.i_end - r.i_begin) * march_nwin(h->g.ny, 64 * s3);
-        const bool force = h->fuse_force || h->fuse_depth >= 2;
-        if (force || h->fuse_chunk > 0 || tiles3 / slots >= 6) {
+        {
             // ONE resident round of units with chain blocks (their units can be as long as the lattice asks for; tools/r3_rounds.sh: 2080 columns 52.9
             // against 55.8 us per step with two rounds of half the length, 3000^2 56.7 / 60.5, 4096^2 90.4 / 92.9); without them two rounds
             // where that leaves at least 12 columns per unit, as in round 2
@@ -678,6 +698,12 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->chain = value != 0.0;
         return rebuild_fuse_plan(h);
     }
+    if (strcmp(name, "plan_columns") == 0) {
+        // a stand-alone handle that stands in for one slab of a split plans like that split's narrowest slab (distributed.measure_slab_cost)
+        if (value < 0) return fail(WT_ERR_ARG, "plan_columns must be >= 0");
+        h->plan_columns = (int)value;
+        return rebuild_fuse_plan(h);
+    }
     if (strcmp(name, "tune") == 0) {
         // measured refinement of the marching units before the first pass on a plan (tune_fuse_plan); 0 keeps the modelled cut
         h->tune = value != 0.0;
@@ -706,6 +732,7 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "chain") == 0) { *value = h->chain ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "fast_math") == 0) { *value = h->fast_math ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "chain_units") == 0) { *value = h->fuse_ready ? h->n_chain_units : 0; return WT_OK; }     // units that run in chain blocks
+    if (strcmp(name, "plan_columns") == 0) { *value = h->plan_columns; return WT_OK; }
     if (strcmp(name, "tune") == 0) { *value = h->tune ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "tune_rounds") == 0) { *value = h->plan_tuned ? h->tune_rounds : 0; return WT_OK; }        // plans measured for the present mask
     if (strcmp(name, "tune_gain") == 0) { *value = h->plan_tuned ? h->tune_gain : 0.0; return WT_OK; }          // makespan modelled plan / kept plan
@@ -1234,6 +1261,13 @@ static int tune_fuse_plan(wt_handle *h, double tau, double u0)
                 if (dur[u] > dur[umax]) umax = u;
             }
             std::sort(cd.begin(), cd.end()); std::sort(sd.begin(), sd.end());
+            for (int pos = 0; pos < 4; pos++) {                   // chain units by their place in the block (outer, inner, inner, outer)
+                std::vector<double> pd;
+                for (int u = pos; u < n; u += 4) if (dur[u] > 0.0 && (h->host_units[u].flags & MU_CHAIN)) pd.push_back(dur[u]);
+                std::sort(pd.begin(), pd.end());
+                if (!pd.empty()) fprintf(stderr, "[wt tune]   chain place %d: %zu units of %d columns, median %.0f p90 %.0f max %.0f\n", pos, pd.size(),
+                                         h->host_units[pos].ib - h->host_units[pos].ia, pd[pd.size() / 2], pd[pd.size() * 9 / 10], pd.back());
+            }
             const MarchUnit &um = h->host_units[umax];
             fprintf(stderr, "[wt tune] round %d: %d units, kernel %.4f ms; chain %zu: median %.0f max %.0f; solo %zu: median %.0f p90 %.0f max %.0f; slowest: window %d columns [%d, %d) flags %d\n",
                     it, n, span, cd.size(), cd.empty() ? 0.0 : cd[cd.size() / 2], cd.empty() ? 0.0 : cd.back(), sd.size(), sd.empty() ? 0.0 : sd[sd.size() / 2],

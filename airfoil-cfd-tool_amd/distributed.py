@@ -72,6 +72,8 @@ def measure_slab_cost(mask: np.ndarray, edges: List[int], rank: int, halo: int, 
     with Engine(hi - lo, mask.shape[0], dtype=dtype, device=device) as e:
         for k, v in (options or {}).items():
             e.set_option(k, v)
+        # every slab of a tunnel takes the steps per pass its NARROWEST slab allows: plan this stand-in the same way
+        e.set_option("plan_columns", min(b - a for a, b in zip(edges[:-1], edges[1:])) + halo)
         e.set_mask(np.ascontiguousarray(mask[:, lo:hi]))
         e.init_equilibrium(u0)
         e.step(24, tau, u0)

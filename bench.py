@@ -171,7 +171,9 @@ def pmc_traffic_this_session(args):
     per_kernel = {}
     tmp = tempfile.mkdtemp(prefix="wt_pmc_", dir="/tmp")
     try:
-        env = dict(os.environ, TMPDIR="/tmp")
+        # WT_TUNE=0: the counters are averaged per kernel over ALL dispatches of the child run, and the trial passes of the measured cut
+        # (13 per new mask, every one with the halo kernel's gather path) would be averaged in; the modelled cut moves the same bytes per pass
+        env = dict(os.environ, TMPDIR="/tmp", WT_TUNE="0")
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             r = subprocess.run([rocprof, "--pmc", counter, "-d", out, "-o", "c", "--"] + child, cwd="/tmp", env=env, stdout=subprocess.PIPE,

@@ -96,13 +96,20 @@ const char *wt_version(void);
  *       three and four, csrc/step_chain.hpp: the same with workgroups whose units share their edge columns).  fp32 (even NY) and
  *       fp64 handles, whole lattices and slabs, with at least 8 local columns and a lattice below 4 GiB.  Default 1 (environment
  *       WT_FUSE2=0|1|2 overrides at wt_create); handles that are not eligible, or too small for it to pay, stay on k_step.
- *   "fuse_depth" (0 = automatic / 2 / 3 / 4): steps per pass.  Automatic: 4 from eight columns per resident unit up (fp64: 12;
- *       3 below), 2 on narrower fp32 lattices.  A step count that is not a multiple is finished with SHORTER FUSED passes on the
+ *   "fuse_depth" (0 = automatic / 2 / 3 / 4): steps per pass.  Automatic, by columns per resident unit: fp32 3 from one, 4 from eight
+ *       (the slabs of a split: from five); fp64 3 from four, 4 from 12; single steps below (measured: windtunnel.hip rebuild_fuse_plan).
+ *       A step count that is not a multiple is finished with SHORTER FUSED passes on the
  *       same tables (5 = 3 + 2, 4 = 2 + 2 — a remainder of one step is never left behind where two passes fit); single steps only
  *       where not even two exact ghost columns / steps are left.  An fp32 tau for which the fast division is not proved takes
  *       three-step passes on a four-step plan (the IEEE four-step kernel is not built).
  *   "chain" (default 1): plain-fluid workgroups march their four units in alternating directions and hand the edge columns over
  *       through LDS instead of recomputing them (csrc/step_chain.hpp).
+ *   "tune" (default 1): before the first pass on a new plan (new mask, changed option) time its units — a few trial passes into the
+ *       lattice nobody reads, the populations are not touched — and cut the columns again by the measured times; the plan whose
+ *       marching kernel ran fastest is kept, the modelled one included (windtunnel.hip tune_fuse_plan; 5-8 ms per mask on 4096^2).
+ *       0 keeps the modelled cut.  Reported afterwards: "tune_rounds" (plans measured), "tune_gain" (modelled / kept kernel time).
+ *   "plan_columns" (default 0 = this handle's): choose the steps per pass as for a lattice of that many local columns — a stand-alone
+ *       handle that stands in for one slab of a split plans like that split's narrowest slab (distributed.measure_slab_cost).
  *   "fuse_chunk": cost limit of one marching unit in columns (0 = the default: units cut by TIME into one resident round).
  *   "fuse_sites": kept for callers of round 2; the sites per lane are fixed by the element type (fp32 2, fp64 1).
  *   "fast_div" (default 1): divide by tau through a reciprocal and two fused multiply-adds where an exhaustive on-device check over
@@ -113,7 +120,7 @@ const char *wt_version(void);
  *       tolerance against the oracle (|d rho| <= 1e-5, |d u| <= 5e-6; tests/test_gpu_fast_math.py), +19 % on 4096^2, +36 % on a
  *       544-column slab.  k_step (single steps, HBM-bound) keeps the reference arithmetic.
  * wt_get_option also reports "fuse_active", "fuse_units", "chain_units", "fuse_depth" / "fuse_sites" (in use), "fuse_tiles_general",
- * "fast_div_active", "passes" and "single_steps" (fused passes / whole k_step steps since the last init or wt_write_f). */
+ * "fast_div_active", "tune_rounds", "tune_gain", "passes" and "single_steps" (fused passes / whole k_step steps since the last init or wt_write_f). */
 int wt_set_option(wt_handle *h, const char *name, double value);
 int wt_get_option(const wt_handle *h, const char *name, double *value);
 

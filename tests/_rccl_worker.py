@@ -23,8 +23,9 @@ def main():
     chunks = [1, 2, 3, 40, 17]
     mask = pkg.geometry.build_geometry(nx, ny, 9.0, None, "naca4412").mask
     ok = True
-    for dtype, depth in (("float32", 0), ("float32", 2), ("float64", 0)):
-        eng = pkg.Engine(nx, ny, dtype=dtype, device=local, rank=rank, nranks=world, halo=halo)
+    uneven = [0] + [int(nx * (0.30 + 0.40 * k / (world - 1))) for k in range(world - 1)] + [nx]     # slabs cut by the caller (wt_create_slab_at)
+    for dtype, depth, edges in (("float32", 0, None), ("float32", 2, None), ("float64", 0, None), ("float32", 0, uneven)):
+        eng = pkg.Engine(nx, ny, dtype=dtype, device=local, rank=rank, nranks=world, halo=halo, edges=edges)
         if depth:
             eng.set_option("fuse_depth", depth)
         eng.set_option("fuse_steps", 2)
@@ -50,7 +51,7 @@ def main():
             same = (np.array_equal(fa.view(np.uint8), fr.view(np.uint8))
                     and all(np.array_equal(np.concatenate([g[i] for g in gathered], axis=1).view(np.uint8), m.view(np.uint8))
                             for i, m in ((1, r0), (2, u0), (3, v0))))
-            print(f"rccl slabs {dtype} depth={depth or 'auto'} world={world}: {'PASS' if same else 'FAIL'}", flush=True)
+            print(f"rccl slabs {dtype} depth={depth or 'auto'} world={world} edges={edges or 'equal'}: {'PASS' if same else 'FAIL'}", flush=True)
             ok &= bool(same)
     flag = torch.tensor([1 if ok else 0], device=torch.device("cuda", local))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -32,7 +32,8 @@ def test_bench_json_contract():
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0            # un-fused on this small lattice: k_step
+    # (k_step is HBM-bound, the marching kernels are bound by their vector instructions; this lattice sits at the edge of the automatic choice)
+    assert r["bound"] == ("valu" if d["config"]["fuse_steps"] else "hbm") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     # (--pmc-traffic 0 and) no rocprofv3 counter entry exists for this lattice: `frac` is null, never the effective figure
     assert r["frac"] is None and r["achieved"] is None and r["traffic"] is None
     assert 0 < r["compulsory_frac"] <= 1.0 and abs(r["compulsory_frac"] - r["compulsory_gbps"] / r["peak"]) < 1e-12

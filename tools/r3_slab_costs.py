@@ -12,14 +12,16 @@ import airfoil_cfd_tool_amd as pkg
 nx = ny = 4096
 halo = 16
 rounds = int(os.environ.get("WT_BALANCE_ROUNDS", "4"))
+opts = {"fuse_depth": int(os.environ["WT_SLAB_DEPTH"])} if os.environ.get("WT_SLAB_DEPTH") else None
+splits = [int(a) for a in sys.argv[1:]] or [2, 4, 8]
 mask = pkg.geometry.build_geometry(nx, ny, 10.0, None, "naca6409").mask
 with pkg.Engine(nx, ny) as e:
     e.set_mask(mask); e.init_equilibrium(0.06); e.step(24, 0.58, 0.06)
     whole = e.step_timed(408, 0.58, 0.06) / 408 * 1e3
     gain = e.get_option("tune_gain")
 print(f"whole 4096^2 lattice on one GPU: {whole:.2f} us/step = {nx * ny / whole / 1e3:.1f} GLUPS (tune gain {gain:.3f})")
-for P in (2, 4, 8):
-    best, hist = pkg.balance_split(nx, P, 32, lambda ed: [pkg.measure_slab_cost(mask, ed, r, halo, steps=408) for r in range(P)], rounds)
+for P in splits:
+    best, hist = pkg.balance_split(nx, P, 32, lambda ed: [pkg.measure_slab_cost(mask, ed, r, halo, steps=408, options=opts) for r in range(P)], rounds)
     for k, (ed, cost) in enumerate(hist):
         worst = max(cost)
         tag = "equal widths" if k == 0 else f"cut by cost, round {k}"
