@@ -245,8 +245,8 @@ struct UnitClock {
     unsigned long long *clk;
     int u, lane;
     unsigned long long t0;
-    __device__ UnitClock(unsigned long long *clk_, int u_, int lane_) : clk(clk_), u(u_), lane(lane_), t0(clk_ ? __builtin_amdgcn_s_memtime() : 0ULL) {}
-    __device__ ~UnitClock()
+    __device__ __forceinline__ UnitClock(unsigned long long *clk_, int u_, int lane_) : clk(clk_), u(u_), lane(lane_), t0(clk_ ? __builtin_amdgcn_s_memtime() : 0ULL) {}
+    __device__ __forceinline__ ~UnitClock()
     {
         if (clk) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
