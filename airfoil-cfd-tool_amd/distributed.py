@@ -98,6 +98,39 @@ def balance_split(nx: int, nranks: int, min_width: int, measure: Callable[[List[
     return best[0], history
 
 
+def balance_over_group(nx: int, min_width: int, measure_mine: Callable[[List[int], int], float], rounds: int = 3, group=None):
+    """balance_split over a torch.distributed process group — COLLECTIVE: every rank calls it with the same arguments.  `measure_mine(edges,
+    rank)` times this rank's slab of a candidate split (measure_slab_cost on its own GPU: no communicator involved); the P costs are
+    all-gathered, so every rank cuts the same edges.  A rank whose measurement raises reports that, and then EVERY rank falls back to equal
+    widths: returns (None, []) everywhere, never a split only some ranks know."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+    class _Failed(RuntimeError):
+        pass
+
+    def measure(edges):
+        ok, mine = 1.0, 0.0
+        try:
+            mine = float(measure_mine(edges, rank))
+        except Exception as e:      # noqa: BLE001 - whatever it is, the other ranks must learn of it
+            print(f"[balance rank {rank}] slab measurement failed: {e}", flush=True)
+            ok = 0.0
+        t = torch.tensor([mine, ok], dtype=torch.float64, device=dev)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t, group=group)
+        if min(float(g[1]) for g in got) < 1.0:
+            raise _Failed("a rank could not measure its slab")
+        return [float(g[0]) for g in got]
+
+    try:
+        return balance_split(nx, world, min_width, measure, rounds)
+    except (_Failed, ValueError):       # (ValueError: the slabs do not fit — computed from gathered numbers, the same on every rank)
+        return None, []
+
+
 def _default_engine_factory(nx, ny, dtype, device, rank, nranks, halo, edges=None):
     from ._capi import Engine
     return Engine(nx, ny, dtype=dtype, device=device, rank=rank, nranks=nranks, halo=halo, edges=edges)
@@ -185,10 +218,14 @@ class SlabWindTunnel(WindTunnel):
         import torch
         dev = self._tensor_device()
         mine = torch.from_numpy(np.ascontiguousarray(np.moveaxis(local, -1, 0))).to(dev)   # [width, ..., NY]
+        wmax = max(w for _, w in self.bounds)
+        if mine.shape[0] < wmax:                 # gather wants one size on every rank: slabs of unequal width are padded, then trimmed
+            pad = torch.zeros((wmax - mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=dev)
+            mine = torch.cat([mine, pad], dim=0)
         if self.rank == dst:
-            bufs = [torch.empty((w,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=dev) for _, w in self.bounds]
+            bufs = [torch.empty_like(mine) for _ in self.bounds]
             self._dist.gather(mine, bufs, dst=self._global_rank(dst), group=self.group)
-            full = torch.cat(bufs, dim=0).cpu().numpy()
+            full = torch.cat([b[:w] for b, (_, w) in zip(bufs, self.bounds)], dim=0).cpu().numpy()
             return np.ascontiguousarray(np.moveaxis(full, 0, -1))
         self._dist.gather(mine, None, dst=self._global_rank(dst), group=self.group)
         return None

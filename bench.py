@@ -419,27 +419,16 @@ def main():
     rounds = (3 if args.balance < 0 else args.balance) if (distributed and args.scaling == "strong") else 0
     if rounds > 0:
         # every rank times ITS slab of the candidate split alone on its GPU (no communicator involved), the costs are gathered, the
-        # columns are cut again; a failure anywhere leaves every rank on equal widths
-        def measure(ed):
-            ok, mine = 1.0, 0.0
-            try:
-                mine = wtpkg.measure_slab_cost(mask, ed, rank, args.halo, dtype=args.dtype, device=local_rank, tau=args.tau, u0=args.u0,
-                                               options=slab_options(args))
-            except Exception as e:      # noqa: BLE001
-                print(f"[bench rank {rank}] slab measurement failed: {e}", file=sys.stderr, flush=True)
-                ok = 0.0
-            t = torch.tensor([mine, ok], dtype=torch.float64, device="cuda")
-            got = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(got, t)
-            if min(float(g[1]) for g in got) < 1.0:
-                raise RuntimeError("a rank could not measure its slab")
-            return [float(g[0]) for g in got]
+        # columns are cut again; a failure anywhere leaves every rank on equal widths (distributed.balance_over_group)
         try:
-            edges, balance_hist = wtpkg.balance_split(nx_total, world, max(args.halo, 32), measure, rounds)
-        except Exception as e:      # noqa: BLE001 - the same exception on every rank (the flag above is gathered)
-            if rank == 0:
-                print(f"[bench] slab balancing skipped: {e}", file=sys.stderr, flush=True)
+            edges, balance_hist = wtpkg.balance_over_group(
+                nx_total, max(args.halo, 32), lambda ed, r: wtpkg.measure_slab_cost(mask, ed, r, args.halo, dtype=args.dtype, device=local_rank, tau=args.tau,
+                                                                                     u0=args.u0, options=slab_options(args)), rounds)
+        except Exception as e:      # noqa: BLE001 - host logic on gathered (identical) numbers: the same outcome on every rank
+            print(f"[bench rank {rank}] slab balancing failed: {e}", file=sys.stderr, flush=True)
             edges, balance_hist = None, []
+        if edges is None and rank == 0:
+            print("[bench] slab balancing skipped: a rank could not measure its slab; equal widths", file=sys.stderr, flush=True)
 
     try:
         if distributed:

@@ -65,6 +65,36 @@ def main():
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     ok &= bool(torch.equal(lo, hi))
+
+    # ---- slabs cut by cost: the collective balancing gives every rank the same split, a failing rank sends ALL ranks back to equal widths,
+    #      and a tunnel on an uneven split equals the monolithic oracle
+    from airfoil_cfd_tool_amd.distributed import balance_over_group, slab_edges
+    dens = np.ones(4096); dens[1000:3000] = 2.5
+    edges, hist = balance_over_group(4096, 32, lambda ed, r: 5.0 + 0.02 * dens[ed[r]:ed[r + 1]].sum(), rounds=3)
+    every = [None] * world
+    dist.all_gather_object(every, (edges, [h[1] for h in hist]))
+    ok &= all(e == every[0] for e in every) and edges is not None and edges[0] == 0 and edges[-1] == 4096 and len(edges) == world + 1
+    ok &= min(max(c) for _, c in hist) <= max(hist[0][1]) and hist[0][0] == slab_edges(4096, world)
+    calls = {"n": 0}
+
+    def flaky(ed, r):
+        calls["n"] += 1
+        if r == world - 1 and calls["n"] == 2:
+            raise RuntimeError("no GPU here")
+        return 1.0 + r
+    e2, h2 = balance_over_group(4096, 32, flaky, rounds=3)
+    ok &= e2 is None and h2 == []
+    uneven = [0] + [int(nx * (0.2 + 0.5 * k / max(1, world - 1))) for k in range(world - 1)] + [nx]
+    wt2 = SlabWindTunnel(shape="naca4412", nx=nx, ny=ny, aoa_deg=9.0, halo=halo, engine_factory=OracleSlabEngine, edges=uneven)
+    ok &= [b[0] for b in wt2.bounds] == uneven[:-1]
+    wt2.sim_step(2 * halo + 3)
+    f2 = wt2.read_f()
+    if rank == 0:
+        import airfoil_cfd_tool_amd.geometry as geo
+        fr2, _ = oracle.run(geo.build_geometry(nx, ny, 9.0, None, "naca4412").mask, 2 * halo + 3, 0.58, 0.06, np.float32)
+        same = bool(np.array_equal(f2, fr2))
+        print("rank0 uneven split", "PASS" if same else "FAIL", flush=True)
+        ok &= same
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

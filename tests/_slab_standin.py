@@ -13,10 +13,10 @@ import lbm_numpy as oracle
 
 
 class OracleSlabEngine:
-    def __init__(self, nx, ny, dtype, device, rank, nranks, halo):
+    def __init__(self, nx, ny, dtype, device, rank, nranks, halo, edges=None):
         self.nx_global, self.ny, self.dtype = nx, ny, np.dtype(dtype)
         self.rank, self.nranks, self.halo = rank, nranks, halo if nranks > 1 else 0
-        edges = [r * nx // nranks for r in range(nranks + 1)]
+        edges = [r * nx // nranks for r in range(nranks + 1)] if edges is None else list(edges)      # wt_create_slab / wt_create_slab_at
         self.x0, self.width = edges[rank], edges[rank + 1] - edges[rank]
         self.gl = self.halo if rank > 0 else 0
         self.gr = self.halo if rank < nranks - 1 else 0
