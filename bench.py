@@ -68,8 +68,9 @@ def parse_args():
     ap.add_argument("--aoa", type=float, default=10.0)
     ap.add_argument("--u0", type=float, default=0.06)
     ap.add_argument("--tau", type=float, default=0.58)
-    ap.add_argument("--halo", type=int, default=16,
-                    help="ghost columns per interior slab side (exchange every `halo` steps; 16 = one single refresh step + five three-step passes)")
+    ap.add_argument("--halo", type=int, default=17,
+                    help="ghost columns per interior slab side (exchange every `halo` steps; 17 = one single refresh step + four four-step passes: "
+                         "2 %% faster than 16 = 1 + 4 + 4 + 4 + 3 in a locally linked group, profiles/r03_g_group_vs_alone.txt)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the NumPy CPU baseline (0 = skip)")
     ap.add_argument("--fuse", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="two steps per pass over the lattice (csrc/step_march.hpp; fp32; bit-identical): -1 library "
