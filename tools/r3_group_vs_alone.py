@@ -9,8 +9,11 @@ mask = pkg.geometry.build_geometry(nx, ny, 10.0, None, "naca6409").mask
 splits = {"equal": pkg.slab_edges(nx, P),
           "cut by cost": [0, 682, 1206, 1634, 2033, 2452, 2884, 3418, 4096],
           "mild": [0, 560, 1080, 1580, 2060, 2540, 3030, 3540, 4096]}
+only = os.environ.get("WT_SPLIT")
 for name, edges in splits.items():
-    alone = [pkg.measure_slab_cost(mask, edges, r, halo, steps=408) for r in range(P)]
+    if only and name != only:
+        continue
+    alone = [pkg.measure_slab_cost(mask, edges, r, halo, steps=408) for r in range(P)] if not only else [0.0] * P
     es = [pkg.Engine(nx, ny, rank=r, nranks=P, halo=halo, edges=edges) for r in range(P)]
     try:
         pkg.Engine.link_local(es)
