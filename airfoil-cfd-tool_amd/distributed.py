@@ -140,7 +140,7 @@ class SlabWindTunnel(WindTunnel):
     """The :class:`WindTunnel` surface for a lattice sharded over the ranks of a process group.
     Every method is collective: all ranks call it with the same arguments."""
 
-    def __init__(self, coords=None, name: str = "", *, halo: int = 16, device: Optional[int] = None, group=None,
+    def __init__(self, coords=None, name: str = "", *, halo: int = 17, device: Optional[int] = None, group=None,
                  engine_factory: Callable = _default_engine_factory, nx: int = 4096, ny: int = 2048, edges: Optional[List[int]] = None,
                  **kwargs):
         """edges: the split (nranks + 1 rising column indices, the same on every rank; see balanced_edges), None for equal widths."""
@@ -321,9 +321,9 @@ class _LocalSlabEngine:
 
 class LocalSlabWindTunnel(WindTunnel):
     """:class:`WindTunnel` over several GPUs driven by ONE process (no torch.distributed, no RCCL):
-    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=16, nx=8192, ny=4096)``."""
+    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=17, nx=8192, ny=4096)``."""
 
-    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: int = 16, edges=None, **kwargs):
+    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: int = 17, edges=None, **kwargs):
         self.devices = [int(d) for d in devices]
         self.halo = int(halo)
         self.edges = None if edges is None else [int(e) for e in edges]
