@@ -312,18 +312,20 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     T feq0[9];
     feq_all<T>(T(1), p.U0, T(0), feq0);
 
-    // classes of columns ia-PAD .. ib+PAD-1 (lane l <-> column ia-PAD+l): two 64-bit scalars
+    // classes of columns ia-PAD .. ib+PAD-1 (lane l <-> columns ia-PAD+l and ia-PAD+64+l): two ballots each (ClassMask), up to 128 columns
     constexpr int PAD = DEPTH == 4 ? 3 : 2;
-    unsigned long long nonfast_m, solid_m;
+    ClassMask nonfast_m, solid_m;
     {
         const int n = ib - ia + 2 * PAD;
         const int col = ia - PAD + lane;
-        uint8_t cls = WC_FAST;
+        uint8_t cls = WC_FAST, cls2 = WC_FAST;
         if (lane < n && col >= -1 && col <= g.nxl) cls = p.wcls[(long)w * (g.nxl + 2) + col + 1];
-        nonfast_m = __ballot(cls != WC_FAST);
-        solid_m = __ballot(cls == WC_SOLID);
+        if (lane + 64 < n && col + 64 >= -1 && col + 64 <= g.nxl) cls2 = p.wcls[(long)w * (g.nxl + 2) + col + 64 + 1];
+        nonfast_m.lo = __ballot(cls != WC_FAST); nonfast_m.hi = __ballot(cls2 != WC_FAST);
+        solid_m.lo = __ballot(cls == WC_SOLID); solid_m.hi = __ballot(cls2 == WC_SOLID);
     }
-    const bool lean = nonfast_m == 0ULL && ia + g.gi0 >= PAD + 1 && ib + g.gi0 <= g.nx_g - PAD - 1 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
+    const ClassMask no_m{0ULL, 0ULL};
+    const bool lean = (nonfast_m.lo | nonfast_m.hi) == 0ULL && ia + g.gi0 >= PAD + 1 && ib + g.gi0 <= g.nx_g - PAD - 1 && !(uflags & MU_OUTLET_AFTER) && !(p.rev & 2);
     if constexpr (DEPTH >= 3) {
         // chain blocks (step_chain.hpp): the four waves of this workgroup share the edge columns of their units through LDS.  The flag is
         // per block (set by chain_blocks on the host for all four units or none), so the barriers inside are workgroup-uniform.
@@ -348,13 +350,13 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     }
     if (DEPTH == 4) {
         constexpr int FDP = sizeof(T) == 4 ? (FD | MARCH_FD_PACKED) : FD;     // fp32: the packed two-site collision (step_march.hpp)
-        if (lean) march_unit4<false, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        if (lean) march_unit4<false, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
         else march_unit4<true, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     } else if (DEPTH == 3) {
-        if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
         else march_unit3<true, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     } else {
-        if (lean) march_unit3_d2<false, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, 0ULL, 0ULL, feq0);
+        if (lean) march_unit3_d2<false, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
         else march_unit3_d2<true, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     }
 }

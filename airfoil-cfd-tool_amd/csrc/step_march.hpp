@@ -54,7 +54,12 @@
 
 namespace wt {
 
-static constexpr int MARCH_MAX_CHUNK = 60;       // class bytes of columns ia-1 .. ib+1 must fit one wave
+static constexpr int MARCH_MAX_CHUNK = 60;       // two-step kernel: class bytes of columns ia-1 .. ib+1 must fit one wave (one ballot)
+static constexpr int MARCH3_MAX_CHUNK = 124;     // three / four steps per pass: two ballots (ClassMask), columns ia-PAD .. ib+PAD-1 <= 128
+
+// classes of up to 128 consecutive columns of a window, one bit each (lane l of the first ballot <-> the first column + l, of the second + 64 + l)
+struct ClassMask { unsigned long long lo, hi; };
+__device__ __forceinline__ bool cm_bit(const ClassMask &m, int idx) { return (((idx < 64) ? (m.lo >> idx) : (m.hi >> (idx - 64))) & 1ULL) != 0; }
 
 enum : uint8_t { WC_FAST = 0, WC_GENERAL = 1, WC_SOLID = 2 };
 

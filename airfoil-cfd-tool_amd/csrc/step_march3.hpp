@@ -445,15 +445,15 @@ __device__ __forceinline__ void seam3_flush(const March3Addr<T, S> &m, int col, 
 
 template <bool BODY, bool EMIT, int FD, typename T, int S>
 __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, __amdgpu_buffer_rsrc_t rh2, unsigned hoff,
-                                            int ia, int ib, int uflags, int j0, int lane, bool far_win, unsigned long long nonfast_m,
-                                            unsigned long long solid_m, const T (&feq0)[9])
+                                            int ia, int ib, int uflags, int j0, int lane, bool far_win, ClassMask nonfast_m,
+                                            ClassMask solid_m, const T (&feq0)[9])
 {
     typedef MV<T, S> V3;
     constexpr unsigned HREC = 8 * sizeof(T);     // bytes of one halo-table record
     const Geom &g = p.g;
     const MarchAddr<T, S> &a = m.a;
-#define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 2)) & 1ULL) != 0)
-#define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 2)) & 1ULL) != 0)
+#define NONFAST(x) (BODY && cm_bit(nonfast_m, (x) - ia + 2))
+#define ALLSOLID(x) (BODY && cm_bit(solid_m, (x) - ia + 2))
 #define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
 #define STEP1P(x, in, G, sb) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, BODY ? (sb).v : nullptr)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
@@ -583,15 +583,15 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 template <bool BODY, bool EMIT, int FD, typename T, int S>
 __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, __amdgpu_buffer_rsrc_t rh2,
                                             __amdgpu_buffer_rsrc_t rh3, unsigned hoff, int ia, int ib, int uflags, int j0, int lane, bool far_win,
-                                            unsigned long long nonfast_m, unsigned long long solid_m, const T (&feq0)[9])
+                                            ClassMask nonfast_m, ClassMask solid_m, const T (&feq0)[9])
 {
     typedef MV<T, S> V3;
     constexpr unsigned HREC = 8 * sizeof(T);
     const Geom &g = p.g;
     const MarchAddr<T, S> &a = m.a;
     // (the level-4 stage of the first iteration works on column ia-4, outside the masks: no class -> plain / inlet branch, no mask access)
-#define NONFAST(x) (BODY && (x) >= ia - 3 && ((nonfast_m >> ((x) - ia + 3)) & 1ULL) != 0)
-#define ALLSOLID(x) (BODY && (x) >= ia - 3 && ((solid_m >> ((x) - ia + 3)) & 1ULL) != 0)
+#define NONFAST(x) (BODY && (x) >= ia - 3 && cm_bit(nonfast_m, (x) - ia + 3))
+#define ALLSOLID(x) (BODY && (x) >= ia - 3 && cm_bit(solid_m, (x) - ia + 3))
 #define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
 #define HCOL(c) ((unsigned)((c) > 0 ? (c) : 0) * HREC)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
@@ -714,15 +714,15 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
 // buffer S3), for the one or two steps a step count leaves over after its three-step passes.
 template <bool BODY, bool EMIT, int FD, typename T, int S>
 __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, unsigned hoff, int ia, int ib,
-                                               int uflags, int j0, int lane, bool far_win, unsigned long long nonfast_m, unsigned long long solid_m,
+                                               int uflags, int j0, int lane, bool far_win, ClassMask nonfast_m, ClassMask solid_m,
                                                const T (&feq0)[9])
 {
     typedef MV<T, S> V3;
     constexpr unsigned HREC = 8 * sizeof(T);
     const Geom &g = p.g;
     const MarchAddr<T, S> &a = m.a;
-#define NONFAST(x) (BODY && ((nonfast_m >> ((x) - ia + 2)) & 1ULL) != 0)
-#define ALLSOLID(x) (BODY && ((solid_m >> ((x) - ia + 2)) & 1ULL) != 0)
+#define NONFAST(x) (BODY && cm_bit(nonfast_m, (x) - ia + 2))
+#define ALLSOLID(x) (BODY && cm_bit(solid_m, (x) - ia + 2))
 #define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
     const int xend = ib;         // last column whose level 1 is computed

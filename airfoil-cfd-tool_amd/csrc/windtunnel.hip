@@ -411,7 +411,7 @@ static void cut_units(wt_handle *h, const float *colw, MarchPlan *out)
     static const double alpha = getenv("WT_ALPHA") ? atof(getenv("WT_ALPHA")) : 1.6;
     static const double alpha_solid = getenv("WT_ALPHA_SOLID") ? atof(getenv("WT_ALPHA_SOLID")) : alpha;
     static const int timed = getenv("WT_PLAN_TIMED") ? atoi(getenv("WT_PLAN_TIMED")) : 1;
-    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
+    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH3_MAX_CHUNK - 3 : (depth == 3 ? MARCH3_MAX_CHUNK : MARCH_MAX_CHUNK);
     const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
     const bool by_time = plan_by_time(h);
     const bool chain = depth >= 3 && h->chain;
@@ -609,7 +609,7 @@ static int rebuild_fuse_plan(wt_handle *h)
             if (tiles / target < 12) target = slots;
             if (const char *e = getenv("WT_MARCH_ROUNDS")) { if (atoi(e) > 0) target = atoi(e) * slots; }      // experiments
             if (!h->chain || h->fuse_chunk > 0)
-                while (tiles / target > MARCH_MAX_CHUNK - 6) target += slots;     // a solo unit holds at most MARCH_MAX_CHUNK columns: more rounds
+                while (tiles / target > MARCH3_MAX_CHUNK - 6) target += slots;     // a solo unit holds at most MARCH3_MAX_CHUNK columns: more rounds
             WT_TRY(build_fuse_plan(h, s3, target, depth));
             h->fuse_ready = h->n_units > 0;
             h->pass_cap = two_on_three ? 2 : 0;

@@ -23,7 +23,7 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
             if (body ? r < 600 : r < 2) wcls[(size_t)w * ld + x + 1] = r % 3 == 0 ? WC_SOLID : WC_GENERAL;
         }
     const MarchRange r = depth >= 3 ? march_range3(g, depth) : march_range(g);
-    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH_MAX_CHUNK - 3 : MARCH_MAX_CHUNK;
+    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH3_MAX_CHUNK - 3 : (depth == 3 ? MARCH3_MAX_CHUNK : MARCH_MAX_CHUNK);
     // max_cost > 0 (the fuse_chunk option): the cut by owned columns; otherwise the library's default, the cut by time
     const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
     const bool chain_timed = depth >= 3 && max_cost <= 0 && (timed == 1 || timed == 3);
