@@ -498,7 +498,7 @@ static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &
     if (total(hi) > target_units) lo = hi;
     else {
         // the count is not monotonic in t where a block starts or stops fitting, so scan downwards from a bisection estimate
-        for (int it = 0; it < 40; it++) {
+        for (int it = 0; it < 24; it++) {       // (t to 6e-8 of its range: unit counts change at discrete t)
             const double mid = 0.5 * (lo + hi);
             if (total(mid) <= target_units) hi = mid; else lo = mid;
         }

@@ -1117,7 +1117,7 @@ static inline MarchPlan build_march_plan_timed(const uint8_t *wcls, const Geom &
     double lo = 0.0, hi = (double)max_len * (1.0 + alpha) + over * (1.0 + alpha) + tail + 1.0;
     if (total(hi) > target_units) lo = hi;                     // the length cap forces more units than asked for: longest units
     else {
-        for (int it = 0; it < 40; it++) {
+        for (int it = 0; it < 24; it++) {       // (t to 6e-8 of its range: unit counts change at discrete t)
             const double mid = 0.5 * (lo + hi);
             if (total(mid) <= target_units) hi = mid; else lo = mid;
         }
