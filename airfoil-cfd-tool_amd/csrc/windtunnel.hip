@@ -140,6 +140,11 @@ struct wt_handle {
     long plan_target = 0;
     bool tune = true;                    // option "tune"
     bool plan_tuned = false;
+    // masks that change every few passes (a slider being dragged) are not worth the trial passes: a mask that follows one which lived fewer than
+    // TUNE_LIVE_PASSES passes is timed only once it has lived that long itself
+    long long passes_total = 0, passes_at_mask = 0;
+    long long masks_set = 0;
+    bool tune_deferred = false;
     int tune_rounds = 0;                 // refinements tried for the present plan
     double tune_gain = 0.0;              // makespan of the modelled plan / makespan of the plan kept (unit clocks)
     unsigned long long *d_clk = nullptr;  // unit clocks of tuning passes: two records of n_units {start, end}
@@ -149,6 +154,7 @@ struct wt_handle {
 };
 
 static const int kReduceBlocks = 1024;
+static const long long TUNE_LIVE_PASSES = 16;
 
 template <typename T> static T *fptr(wt_handle *h, int which) { return reinterpret_cast<T *>(h->f[which]); }
 
@@ -786,6 +792,9 @@ extern "C" int wt_set_mask(wt_handle *h, const uint8_t *mask)
     WT_TRY(classify_tiles(h->mask, h->tiles, g, h->tiles_per_col, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     h->mask_set = true;
+    h->tune_deferred = h->masks_set > 0 && h->passes_total - h->passes_at_mask < TUNE_LIVE_PASSES;
+    h->passes_at_mask = h->passes_total;
+    h->masks_set += 1;
     WT_TRY(rebuild_fuse_plan(h));
     return WT_OK;
 }
@@ -1063,6 +1072,7 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
     h->cur = 1 - h->cur;
     h->steps_done += 2;
     h->passes += 1;
+    h->passes_total += 1;
     h->seams_valid = true;                       // the pass wrote the seam rows of the lattice it produced
     if (h->nranks > 1) h->ghost_valid -= 2;      // two columns of ghost validity consumed
     return WT_OK;
@@ -1075,6 +1085,11 @@ static int step_pair_fused(wt_handle *h, double tau, double u0, bool emit)
     bool fd = false;
     WT_TRY(fastdiv_for(h, (float)tau, &fd));
     return fd ? step_pair_fused_t<float, 2, 1>(h, tau, u0, emit) : step_pair_fused_t<float, 2, 0>(h, tau, u0, emit);
+}
+
+static inline bool tune_due(const wt_handle *h, int nsteps)
+{
+    return !h->plan_tuned && nsteps >= 2 && h->fuse_ready && (!h->tune_deferred || h->passes_total - h->passes_at_mask >= TUNE_LIVE_PASSES);
 }
 
 static int ensure_clocks(wt_handle *h)
@@ -1147,6 +1162,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     h->cur = 1 - h->cur;
     h->steps_done += depth;
     h->passes += 1;
+    h->passes_total += 1;
     h->seams_valid = true;
     // One column of ghost validity is consumed per step — and the units of a depth-D plan leave the D-1 columns next to a local edge
     // unwritten whatever the pass advances (march_range3), so a SHORTER pass on those tables still costs D-1 columns of the fresh ghosts
@@ -1217,7 +1233,7 @@ static int tune_fuse_plan(wt_handle *h, double tau, double u0)
     std::vector<unsigned long long> clk;
     std::vector<double> dur, chain_dur;
     const int s_cur = h->cur, s_gv = h->ghost_valid;
-    const long long s_steps = h->steps_done, s_passes = h->passes;
+    const long long s_steps = h->steps_done, s_passes = h->passes, s_total = h->passes_total;
     bool have_best = false, uploaded_best = true;
     for (int it = 0; it < rounds; it++) {
         const int n = h->n_units;
@@ -1231,7 +1247,7 @@ static int tune_fuse_plan(wt_handle *h, double tau, double u0)
             h->passes = rep & 1;                               // the launch order alternates with the pass count
             const int rc = step_fused(h, tau, u0, false, k);
             h->clk_on = false;
-            h->cur = s_cur; h->ghost_valid = s_gv; h->steps_done = s_steps; h->passes = s_passes;
+            h->cur = s_cur; h->ghost_valid = s_gv; h->steps_done = s_steps; h->passes = s_passes; h->passes_total = s_total;
             h->seams_valid = false;                            // the seam rows now describe the lattice that was thrown away
             if (rc != WT_OK) return rc;
             HIP_TRY(hipEventSynchronize(h->ev_t1));
@@ -1329,7 +1345,7 @@ static int set_tau_cap(wt_handle *h, double tau)
 static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
 {
     WT_TRY(set_tau_cap(h, tau));
-    if (!h->plan_tuned && nsteps >= 2 && h->fuse_ready) WT_TRY(tune_fuse_plan(h, tau, u0));
+    if (tune_due(h, nsteps)) WT_TRY(tune_fuse_plan(h, tau, u0));
     int s = 0;
     while (s < nsteps) {
         const int k = fuse_stride(h, nsteps - s);
@@ -1511,7 +1527,7 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
     for (int r = 0; r < n; r++) {
         HIP_TRY(hipSetDevice(hs[r]->device));
         WT_TRY(set_tau_cap(hs[r], tau));
-        if (!hs[r]->plan_tuned && nsteps >= 2 && hs[r]->fuse_ready) WT_TRY(tune_fuse_plan(hs[r], tau, u0));
+        if (tune_due(hs[r], nsteps)) WT_TRY(tune_fuse_plan(hs[r], tau, u0));
     }
     int s = 0;
     while (s < nsteps) {

@@ -107,7 +107,8 @@ const char *wt_version(void);
  *   "tune" (default 1): before the first pass on a new plan (new mask, changed option) time its units — a few trial passes into the
  *       lattice nobody reads, the populations are not touched — and cut the columns again by the measured times; the plan whose
  *       marching kernel ran fastest is kept, the modelled one included (windtunnel.hip tune_fuse_plan; once per mask: 14 ms on 4096^2, 3 ms
- *       on 1024x512).
+ *       on 1024x512; a mask that follows one which lived fewer than 16 passes - a slider being dragged - is timed only once it has
+ *       lived that long itself).
  *       0 keeps the modelled cut.  Reported afterwards: "tune_rounds" (plans measured), "tune_gain" (modelled / kept kernel time).
  *   "plan_columns" (default 0 = this handle's): choose the steps per pass as for a lattice of that many local columns — a stand-alone
  *       handle that stands in for one slab of a split plans like that split's narrowest slab (distributed.measure_slab_cost).

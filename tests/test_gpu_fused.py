@@ -376,8 +376,16 @@ def test_measured_refinement_of_the_units_changes_no_bit(pkg, oracle_c, dtype, d
             assert e.info().steps_done == 1 + depth
             e.step(2 * depth + 1, tau, u0)
             out[tune] = (f1, e.read_f(), e.read_macro(), e.get_option("fuse_units"))
-            # a new mask is timed again, and turning the option off brings the modelled cut back
+            # a mask that follows a short-lived one (a slider being dragged: fewer than 16 passes) is timed only once it has lived that long
+            # itself; a mask that follows a long-lived one is timed at once; turning the option off brings the modelled cut back
             e.set_mask(_body(pkg, nx, ny, aoa=3.0))
+            e.step(depth, tau, u0)
+            assert e.get_option("tune_rounds") == 0
+            e.step(16 * depth, tau, u0)
+            assert e.get_option("tune_rounds") == 0              # (looked at when a stepping call begins)
+            e.step(depth, tau, u0)
+            assert (e.get_option("tune_rounds") > 0) == bool(tune)
+            e.set_mask(_body(pkg, nx, ny, aoa=4.0))
             e.step(depth, tau, u0)
             assert (e.get_option("tune_rounds") > 0) == bool(tune)
             e.set_option("tune", 0)
