@@ -88,7 +88,7 @@ def parse_args():
     ap.add_argument("--balance", type=int, default=-1, metavar="R",
                     help="slab runs with strong scaling: R rounds of cutting the slabs by MEASURED cost instead of equal widths before the run (every rank "
                          "times its candidate slab alone, airfoil_cfd_tool_amd.distributed.balance_split; the split with the fastest slowest slab is kept, "
-                         "the equal one included).  -1 (default): 3 rounds when there is more than one slab, 0: equal widths")
+                         "the equal one included).  -1 (default): 4 rounds when there is more than one slab, 0: equal widths")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
     return ap.parse_args()
@@ -299,7 +299,7 @@ def local_slabs_main(args, wtpkg, mask, body_name):
     P, ny, nx = args.local_slabs, args.ny, args.nx
     torch.cuda.set_device(0)
     edges, history = None, []
-    rounds = 3 if args.balance < 0 else args.balance
+    rounds = 4 if args.balance < 0 else args.balance
     if P > 1 and rounds > 0:
         opts = slab_options(args)
         edges, history = wtpkg.balance_split(nx, P, max(args.halo, 32), lambda ed: [
@@ -417,7 +417,7 @@ def main():
         return local_slabs_main(args, wtpkg, mask, body_name)
 
     edges, balance_hist = None, []
-    rounds = (3 if args.balance < 0 else args.balance) if (distributed and args.scaling == "strong") else 0
+    rounds = (4 if args.balance < 0 else args.balance) if (distributed and args.scaling == "strong") else 0
     if rounds > 0:
         # every rank times ITS slab of the candidate split alone on its GPU (no communicator involved), the costs are gathered, the
         # columns are cut again; a failure anywhere leaves every rank on equal widths (distributed.balance_over_group)
