@@ -76,7 +76,7 @@ def measure_slab_cost(mask: np.ndarray, edges: List[int], rank: int, halo: int, 
         e.set_option("plan_columns", min(b - a for a, b in zip(edges[:-1], edges[1:])) + halo)
         e.set_mask(np.ascontiguousarray(mask[:, lo:hi]))
         e.init_equilibrium(u0)
-        e.step(24, tau, u0)
+        e.step(200, tau, u0)                  # (the plan is timed and cut again here; and an idle GPU's clocks take some 20 ms of work to settle)
         return e.step_timed(steps, tau, u0) / steps * 1e3
 
 

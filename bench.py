@@ -52,8 +52,10 @@ COMM_TIMEOUT_S = 180.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: the clocks of an idle MI355X take 20-30 ms of work to settle (profiles/r03_g_time_series.txt: 98 -> 86 us per step over the first 250 steps
+    # of the bench lattice), so the untimed warm-up covers that and the timed region is 35 ms of steady state
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
