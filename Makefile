@@ -5,14 +5,18 @@ PKG       = airfoil-cfd-tool_amd
 CSRC      = $(PKG)/csrc
 LIB       = $(PKG)/lib/libwindtunnel.so
 # -ffp-contract=off: one rounding per operation, as the oracle (and the parity tests) assume.
-HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function
-LDFLAGS  ?= -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -Wall -Wno-unused-function
+# EXPERIMENT=1: the planner / launch-order environment knobs of tools/ (include/windtunnel.h "Environment"); never for a production build
+ifeq ($(EXPERIMENT),1)
+HIPFLAGS += -DWT_EXPERIMENT_KNOBS
+endif
+LDFLAGS  ?= -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -Wl,--version-script=$(CSRC)/libwindtunnel.map
 
 all: lib oracle
 
 lib: $(LIB)
 
-$(LIB): $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.hpp) include/windtunnel.h
+$(LIB): $(wildcard $(CSRC)/*.hip) $(wildcard $(CSRC)/*.hpp) $(CSRC)/libwindtunnel.map include/windtunnel.h
 	mkdir -p $(PKG)/lib
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/windtunnel.hip $(LDFLAGS)
 

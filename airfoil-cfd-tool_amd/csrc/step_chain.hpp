@@ -406,6 +406,72 @@ static inline void chain_blocks(MarchPlan &pl, const uint8_t *wcls, const Geom &
         for (int k = 0; k < 4; k++) pl.units.push_back(b.u[k]);
 }
 
+// The kernel's hand-over is safe only on a well-formed plan: chain_receive polls an LDS flag that only the partner wave of the same workgroup
+// sets, and a workgroup barrier sits behind `uflags & MU_CHAIN` — a block with three chain units and one solo unit, a chain unit shorter than
+// the pipeline, or two "partners" that are not neighbours would spin for ever or read columns nobody published.  The planners above produce
+// well-formed plans by construction (tests/_march_plan_check.hip); this is the same statement checked on EVERY plan the library uploads
+// (windtunnel.hip upload_units), whoever built it.  A group of four that carries a chain flag must be: four chain units of one window,
+// contiguous, at least depth + 1 columns each, flagged (DIR_NEG | -), (END_SHARED), (DIR_NEG | END_SHARED), (-), none the outlet unit, the
+// footprint (`pad` columns beyond either end) inside the local lattice, clear of the tunnel's ends and FAST throughout.
+static inline bool chain_group_ok(const MarchUnit *u, const uint8_t *wcls, const Geom &g, int depth)
+{
+    const int ld = g.nxl + 2, pad = depth == 4 ? 3 : 2;
+    static const int want[4] = {MU_CHAIN | MU_DIR_NEG, MU_CHAIN | MU_END_SHARED, MU_CHAIN | MU_DIR_NEG | MU_END_SHARED, MU_CHAIN};
+    for (int k = 0; k < 4; k++) {
+        if (u[k].flags != want[k] || u[k].w != u[0].w || u[k].ib - u[k].ia < depth + 1) return false;
+        if (k && u[k].ia != u[k - 1].ib) return false;
+    }
+    const int lo = u[0].ia - pad, hi = u[3].ib + pad;
+    if (lo < 0 || hi > g.nxl || lo + g.gi0 < 1 || hi + g.gi0 > g.nx_g - 1) return false;
+    const uint8_t *c = wcls + (size_t)u[0].w * ld + 1;
+    for (int x = lo; x < hi; x++)
+        if (c[x] != WC_FAST) return false;
+    return true;
+}
+
+// Checks every aligned group of four units; a group that carries chain flags without being a well-formed chain block is DOWNGRADED to solo units
+// (flags cleared; a unit longer than a solo unit may be — its class masks cover max_solo columns — is split), never launched as it is.  Returns the
+// number of groups downgraded; the list stays a whole number of groups (well-formed chain blocks first where anything was rebuilt).
+static inline int sanitize_chain_plan(MarchPlan &pl, const uint8_t *wcls, const Geom &g, int depth, int max_solo)
+{
+    const size_t n = pl.units.size();
+    bool any_chain = false;
+    for (const MarchUnit &u : pl.units) any_chain = any_chain || (u.flags & (MU_CHAIN | MU_DIR_NEG | MU_END_SHARED)) != 0;
+    if (!any_chain) return 0;
+    int bad = 0;
+    std::vector<char> ok((n + 3) / 4, 1);
+    for (size_t b = 0; b < n; b += 4) {
+        int nc = 0;
+        const size_t m = std::min<size_t>(4, n - b);
+        for (size_t k = 0; k < m; k++) nc += (pl.units[b + k].flags & (MU_CHAIN | MU_DIR_NEG | MU_END_SHARED)) != 0;
+        if (nc == 0) continue;
+        if (m < 4 || depth < 3 || !chain_group_ok(&pl.units[b], wcls, g, depth)) { ok[b / 4] = 0; bad++; }
+    }
+    if (bad == 0 && n % 4 == 0) return 0;
+    std::vector<MarchUnit> chain, solo;
+    for (size_t b = 0; b < n; b += 4) {
+        const size_t m = std::min<size_t>(4, n - b);
+        const bool is_chain = ok[b / 4] && m == 4 && (pl.units[b].flags & MU_CHAIN);
+        for (size_t k = 0; k < m; k++) {
+            MarchUnit u = pl.units[b + k];
+            if (is_chain) { chain.push_back(u); continue; }
+            if (u.ib <= u.ia) continue;                               // padding
+            u.flags &= MU_OUTLET_AFTER;
+            const int outlet = u.flags;
+            for (int a = u.ia; a < u.ib;) {
+                int e = std::min(u.ib, a + max_solo);
+                if (e < u.ib && u.ib - e < 2 && u.ib - 2 > a) e = u.ib - 2;      // (a four-step pass wants two columns in a window's last unit)
+                solo.push_back(MarchUnit{a, e, u.w, e == u.ib ? outlet : 0});
+                a = e;
+            }
+        }
+    }
+    while (solo.size() % 4) solo.push_back(MarchUnit{0, 0, solo.empty() ? 0 : solo.back().w, 0});
+    pl.units = chain;
+    pl.units.insert(pl.units.end(), solo.begin(), solo.end());
+    return bad;
+}
+
 // The cut by time (build_march_plan_timed) with chain blocks: sweeping a window from the inlet side, a chain block of four units — outer,
 // inner, inner, outer, with as many columns as the time limit t leaves after the chain overheads — is placed wherever its whole footprint is
 // plain fluid and clear of the tunnel's ends; elsewhere solo units are cut by time as before.  A chain block counts four units, and the

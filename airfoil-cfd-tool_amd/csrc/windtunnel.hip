@@ -28,6 +28,20 @@
 
 using namespace wt;
 
+// Environment knobs.  Five are part of the interface (include/windtunnel.h: WT_FUSE2, WT_FUSE_CHUNK, WT_FAST_DIV, WT_CHAIN, WT_TUNE): they preset a
+// handle's options at wt_create and, like every option that decides the pass schedule, enter the cross-rank fingerprint (schedule_fingerprint).
+// The others belong to the experiments under tools/ and exist only in a library built with -DWT_EXPERIMENT_KNOBS (`make lib EXPERIMENT=1`): a
+// production library cannot be steered into a plan its neighbours do not share by a stray environment variable.
+static inline const char *exp_env(const char *name)
+{
+#ifdef WT_EXPERIMENT_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------
@@ -74,6 +88,8 @@ struct wt_handle {
     int rank = 0, nranks = 1, halo = 0;
     int x0 = 0, width = 0;       // owned global columns [x0, x0+width)
     int min_width = 0;           // owned columns of the narrowest slab of the tunnel
+    int max_width = 0;           // ... and of the widest one (every rank knows both from the split)
+    std::vector<int> edges;      // the split: slab r owns [edges[r], edges[r+1])
     int plan_columns = 0;        // option "plan_columns": choose the steps per pass as for a lattice of this many local columns (0: this one's)
     int gl = 0, gr = 0;          // ghost columns on the left / right
     Geom g{};                    // local geometry
@@ -151,7 +167,26 @@ struct wt_handle {
     size_t clk_cap = 0;
     bool clk_on = false;
     size_t clk_off = 0;
+    long wave_slots = 0;                 // resident marching waves of the device: CUs x 4 SIMDs x 2 (x WT_MARCH_WAVES / 2 in an experiment build)
+    int chain_downgrades = 0;            // groups of four units whose chain flags failed sanitize_chain_plan (option "chain_downgrades"; 0 by construction)
+    // cross-rank agreement (slab handles): everything that decides the sequence of passes / single steps / refreshes must be the same on every
+    // slab of a tunnel — checked, not assumed (agree_rccl / agree_local)
+    bool agree_check = true;             // option "agree_check"
+    bool agree_dirty = true;             // a schedule input changed since the last check
+    long long *d_agree = nullptr;        // device scratch of the all-reduce
+    long long agree_checks = 0;          // checks made (option "agree_checks")
+    float fd_agreed_tau = 0.0f;          // tau whose fast-division verdict the ranks have agreed on
+    bool fd_agreed = false;
+    int comm_ranks = 0;                  // ncclCommCount of the handle's communicator (option "comm_ranks")
+    // exchange timing (option "exchange_timing"; bench.py --gpus N): events around the ghost exchange on the comm stream and around the interior
+    // kernel / the wait for the exchange on the compute stream of every refresh step
+    bool xt_on = false;
+    std::vector<hipEvent_t> xt_ev;       // XT_RING x {x0, x1, i0, i1, w}
+    int xt_n = 0;                        // refreshes recorded and not yet resolved
+    double xt_exchange_ms = 0.0, xt_interior_ms = 0.0, xt_exposed_ms = 0.0;
+    long long xt_count = 0;
 };
+static const int XT_RING = 32;
 
 static const int kReduceBlocks = 1024;
 static const long long TUNE_LIVE_PASSES = 16;
@@ -201,6 +236,8 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     h->rank = rank; h->nranks = nranks;
     // the split: the caller's (wt_create_slab_at) or equal widths; the narrowest slab of all decides the plan depth of every rank
     h->min_width = nx_g;
+    h->max_width = 0;
+    h->edges.assign((size_t)nranks + 1, 0);
     for (int r = 0; r < nranks; r++) {
         const int a = edges ? edges[r] : (int)((long long)r * nx_g / nranks), b = edges ? edges[r + 1] : (int)((long long)(r + 1) * nx_g / nranks);
         if (edges && (a < 0 || b > nx_g || b <= a || (r == 0 && a != 0) || (r == nranks - 1 && b != nx_g))) {
@@ -208,6 +245,8 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
             return fail(WT_ERR_ARG, "edges must rise from 0 to nx_global (slab %d: [%d, %d))", r, a, b);
         }
         if (b - a < h->min_width) h->min_width = b - a;
+        if (b - a > h->max_width) h->max_width = b - a;
+        h->edges[(size_t)r] = a; h->edges[(size_t)r + 1] = b;
         if (r == rank) { h->x0 = a; h->width = b - a; }
     }
     if (nranks > 1 && halo > h->min_width) { delete h; return fail(WT_ERR_ARG, "halo %d wider than the narrowest slab (%d columns)", halo, h->min_width); }
@@ -216,6 +255,14 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     h->gl = (rank > 0) ? h->halo : 0;
     h->gr = (rank < nranks - 1) ? h->halo : 0;
     h->esz = dtype == WT_F32 ? 4 : 8;
+    {
+        int cus = 0;
+        hipError_t ea = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        if (ea != hipSuccess || cus <= 0) { delete h; return fail(WT_ERR_HIP, "hipDeviceGetAttribute(multiprocessor count) failed: %s", hipGetErrorString(ea)); }
+        long waves = 2;                                                  // resident marching waves per SIMD (229-252 VGPRs)
+        if (const char *e = exp_env("WT_MARCH_WAVES")) waves = atoi(e) > 0 ? atoi(e) : 2;
+        h->wave_slots = (long)cus * 4 * waves;
+    }
     Geom &g = h->g;
     g.nxl = h->gl + h->width + h->gr;
     g.ny = ny;
@@ -329,6 +376,8 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->d_units) (void)hipFree(h->d_units);
     if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->d_nbad) (void)hipFree(h->d_nbad);
+    if (h->d_agree) (void)hipFree(h->d_agree);
+    for (hipEvent_t e : h->xt_ev) if (e) (void)hipEventDestroy(e);
     if (h->partials) (void)hipFree(h->partials);
     if (h->partials_host) (void)hipHostFree(h->partials_host);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -370,11 +419,21 @@ extern "C" int wt_sync(wt_handle *h)
 // ------------------------------------------------------------------------------------------
 // whole lattices and column slabs alike (a slab plans over its LOCAL columns, ghosts included); the
 // marching kernels address a lattice through one 32-bit buffer descriptor
+// A slab decides from the SPLIT, not from its own width: the widest slab's lattice (its width + both halos — what an interior
+// slab of that width would hold) must stay below the 4 GiB a buffer descriptor addresses and the narrowest one must have 8 local columns,
+// so that either every rank of a tunnel marches or none does, whatever the cut of the slabs.
+static unsigned long long plane_elems_of(int nxl, long pitch, size_t esz)
+{
+    return (unsigned long long)((((long)(nxl + 2) * pitch * (long)esz + 4095) / 4096 * 4096 + 17408) / (long)esz);
+}
 static bool fuse_eligible_s(const wt_handle *h, int sites)
 {
     const unsigned long long eb = h->dtype == WT_F32 ? 4 : 8;
     if (sites * eb != 8) return false;                                      // 8-byte vectors: fp32 with 2 sites per lane, fp64 with 1
-    return h->g.ny % sites == 0 && h->g.nxl >= 8 && 9ULL * h->g.plane * eb < (1ULL << 32) - (1ULL << 20);
+    const int nxl_max = h->nranks > 1 ? h->max_width + 2 * h->halo : h->g.nxl;
+    const int nxl_min = h->nranks > 1 ? h->min_width + h->halo : h->g.nxl;
+    const unsigned long long plane = std::max<unsigned long long>((unsigned long long)h->g.plane, plane_elems_of(nxl_max, h->g.pitch, (size_t)eb));
+    return h->g.ny % sites == 0 && std::min(h->g.nxl, nxl_min) >= 8 && 9ULL * plane * eb < (1ULL << 32) - (1ULL << 20);
 }
 static bool fuse_eligible(const wt_handle *h) { return fuse_eligible_s(h, h->dtype == WT_F32 ? 2 : 1); }
 static inline int plan_depth(const wt_handle *h) { return h->pass_cap > 0 && h->pass_cap < h->march_depth ? h->pass_cap : h->march_depth; }
@@ -402,7 +461,7 @@ static void free_march_tables(wt_handle *h)
 // costs measured by tune_fuse_plan, or null.
 static bool plan_by_time(const wt_handle *h)
 {
-    static const int timed = getenv("WT_PLAN_TIMED") ? atoi(getenv("WT_PLAN_TIMED")) : 1;
+    static const int timed = exp_env("WT_PLAN_TIMED") ? atoi(exp_env("WT_PLAN_TIMED")) : 1;
     return h->fuse_chunk <= 0 && timed;
 }
 static void cut_units(wt_handle *h, const float *colw, MarchPlan *out)
@@ -414,17 +473,17 @@ static void cut_units(wt_handle *h, const float *colw, MarchPlan *out)
     // four steps per pass: class masks cover ib - ia + 6 columns, and the last unit of a window marches at least two
     // cost of a column that is not plain fluid, in plain columns: 1 + alpha; `over`: columns a unit iterates over beyond its own (pipeline
     // fill and drain of a `depth`-step pass); `tail`: the outlet column's extra stages — see build_march_plan_timed
-    static const double alpha = getenv("WT_ALPHA") ? atof(getenv("WT_ALPHA")) : 1.6;
-    static const double alpha_solid = getenv("WT_ALPHA_SOLID") ? atof(getenv("WT_ALPHA_SOLID")) : alpha;
-    static const int timed = getenv("WT_PLAN_TIMED") ? atoi(getenv("WT_PLAN_TIMED")) : 1;
+    static const double alpha = exp_env("WT_ALPHA") ? atof(exp_env("WT_ALPHA")) : 1.6;
+    static const double alpha_solid = exp_env("WT_ALPHA_SOLID") ? atof(exp_env("WT_ALPHA_SOLID")) : alpha;
+    static const int timed = exp_env("WT_PLAN_TIMED") ? atoi(exp_env("WT_PLAN_TIMED")) : 1;
     const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH3_MAX_CHUNK - 3 : (depth == 3 ? MARCH3_MAX_CHUNK : MARCH_MAX_CHUNK);
     const double over = depth == 4 ? 4.5 : (depth == 3 ? 2.7 : 1.5), tail = depth == 4 ? 1.25 : (depth == 3 ? 1.0 : 0.5);
     const bool by_time = plan_by_time(h);
     const bool chain = depth >= 3 && h->chain;
     // chain overheads in columns, from per-unit clocks on a 544-column lattice (tools/unit_clocks.py): a four-step chain unit of 8.5 columns takes as
     // long as 10.5 solo iterations, a three-step one as 9.9
-    static const double beta = getenv("WT_BETA") ? atof(getenv("WT_BETA")) : 1.25;
-    static const int max_chain = getenv("WT_MAX_CHAIN") ? atoi(getenv("WT_MAX_CHAIN")) : 160;
+    static const double beta = exp_env("WT_BETA") ? atof(exp_env("WT_BETA")) : 1.25;
+    static const int max_chain = exp_env("WT_MAX_CHAIN") ? atoi(exp_env("WT_MAX_CHAIN")) : 160;
     const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, beta, 0.6, max_chain, alpha_solid};
     MarchPlan pl = !by_time ? build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, timed ? alpha : 4.0, &r, min_last, max_len, chain ? 4 : 1)
                    : chain  ? build_chain_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, depth, cc, colw)
@@ -433,8 +492,15 @@ static void cut_units(wt_handle *h, const float *colw, MarchPlan *out)
     *out = std::move(pl);
 }
 
-static int upload_units(wt_handle *h, const MarchPlan &pl)
+static int upload_units(wt_handle *h, const MarchPlan &plan_in)
 {
+    // the chain-block invariant the kernel's LDS hand-over rests on, checked on every plan that reaches the device (sanitize_chain_plan,
+    // step_chain.hpp): an ill-formed group is downgraded to solo units and counted, never launched
+    MarchPlan pl = plan_in;
+    if (!h->host_wcls.empty()) {
+        const int max_solo = (h->march_depth == 4 ? MARCH3_MAX_CHUNK - 3 : (h->march_depth == 3 ? MARCH3_MAX_CHUNK : MARCH_MAX_CHUNK)) - 2;
+        h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), h->g, h->march_depth, max_solo);
+    }
     h->n_chain_units = 0;
     for (const MarchUnit &u : pl.units) h->n_chain_units += (u.flags & MU_CHAIN) != 0;
     const size_t total = pl.units.size();
@@ -560,11 +626,7 @@ static int rebuild_fuse_plan(wt_handle *h)
     h->n_units = h->nonfast_tiles = 0;
     h->pass_cap = 0;
     if (!h->fuse || !fuse_eligible(h) || !h->mask_set) return WT_OK;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, h->device));
-    long waves = 2;                                                      // resident marching waves per SIMD
-    if (const char *e = getenv("WT_MARCH_WAVES")) waves = atoi(e) > 0 ? atoi(e) : 2;
-    const long slots = (long)prop.multiProcessorCount * 4 * waves;
+    const long slots = h->wave_slots;
     const int s3 = h->dtype == WT_F32 ? 2 : 1;
     const bool two_on_three = h->dtype != WT_F32 && h->fuse_depth == 2;  // fp64: two-step passes on the three-step tables
     // Every slab of a tunnel must take the SAME sequence of passes and refresh steps (the exchange is collective: over RCCL each rank
@@ -595,9 +657,9 @@ static int rebuild_fuse_plan(wt_handle *h)
         const long tiles3 = (long)(plan_nxl - 4) * march_nwin(h->g.ny, 64 * s3);
         const bool f32 = h->dtype == WT_F32;
         const long cpu = tiles3 / slots;
-        static const long min4_env = getenv("WT_DEPTH4_MIN") ? atol(getenv("WT_DEPTH4_MIN")) : 0;      // experiments
+        static const long min4_env = exp_env("WT_DEPTH4_MIN") ? atol(exp_env("WT_DEPTH4_MIN")) : 0;      // experiments
         const long min4 = min4_env > 0 ? min4_env : ((h->nranks > 1 || h->plan_columns > 0) ? 5 : 8);
-        static const long min3 = getenv("WT_DEPTH3_MIN") ? atol(getenv("WT_DEPTH3_MIN")) : 1;
+        static const long min3 = exp_env("WT_DEPTH3_MIN") ? atol(exp_env("WT_DEPTH3_MIN")) : 1;
         const bool force = h->fuse_force || h->fuse_depth >= 2;
         if (!force && h->fuse_chunk <= 0 && cpu < (f32 ? min3 : 4)) return WT_OK;
         int depth = h->fuse_depth == 4 || (h->fuse_depth == 0 && cpu >= (f32 ? min4 : 12)) ? 4 : 3;
@@ -613,7 +675,7 @@ static int rebuild_fuse_plan(wt_handle *h)
             // where that leaves at least 12 columns per unit, as in round 2
             long target = h->chain && h->fuse_chunk <= 0 ? slots : 2 * slots;
             if (tiles / target < 12) target = slots;
-            if (const char *e = getenv("WT_MARCH_ROUNDS")) { if (atoi(e) > 0) target = atoi(e) * slots; }      // experiments
+            if (const char *e = exp_env("WT_MARCH_ROUNDS")) { if (atoi(e) > 0) target = atoi(e) * slots; }      // experiments
             if (!h->chain || h->fuse_chunk > 0)
                 while (tiles / target > MARCH3_MAX_CHUNK - 6) target += slots;     // a solo unit holds at most MARCH3_MAX_CHUNK columns: more rounds
             WT_TRY(build_fuse_plan(h, s3, target, depth));
@@ -635,7 +697,7 @@ two_step:
 }
 
 #ifdef WT_M3_STAMPS          // diagnostic build only (tools/m3_stamps.py); not part of the ABI
-extern "C" int wt_debug_m3_stamps(unsigned long long *out, int reset)
+extern "C" WT_API int wt_debug_m3_stamps(unsigned long long *out, int reset)
 {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(wt::g_m3_stamps), 8 * sizeof(unsigned long long)));
@@ -645,14 +707,14 @@ extern "C" int wt_debug_m3_stamps(unsigned long long *out, int reset)
 #endif
 
 #ifdef WT_UNIT_CLOCKS         // diagnostic build only (tools/unit_clocks.py); not part of the ABI
-extern "C" int wt_debug_halo_clocks(unsigned long long *out, int reset)
+extern "C" WT_API int wt_debug_halo_clocks(unsigned long long *out, int reset)
 {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(wt::g_halo_clk), 8 * sizeof(unsigned long long)));
     if (reset) { unsigned long long z[8] = {0}; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(wt::g_halo_clk), z, sizeof(z))); }
     return WT_OK;
 }
-extern "C" int wt_debug_unit_clocks(wt_handle *h, unsigned long long *clk, int *units4, int cap)
+extern "C" WT_API int wt_debug_unit_clocks(wt_handle *h, unsigned long long *clk, int *units4, int cap)
 {
     WT_TRY(check_handle(h));
     HIP_TRY(hipDeviceSynchronize());
@@ -664,11 +726,53 @@ extern "C" int wt_debug_unit_clocks(wt_handle *h, unsigned long long *clk, int *
 }
 #endif
 
+// Exchange timing: slot k of the ring holds the events of one refresh step — x0 / x1 around the exchange on the comm stream, i0 / i1 around the
+// interior kernel and w behind the wait for the exchange on the compute stream.  exposed = i1 -> w: what the compute stream waited for the
+// exchange after its interior kernel (a few microseconds of event overhead even when the exchange hid completely).
+static inline hipEvent_t xt_event(wt_handle *h, int which) { return h->xt_ev[(size_t)(h->xt_n % XT_RING) * 5 + which]; }
+static int xt_resolve(wt_handle *h)
+{
+    if (h->xt_ev.empty() || h->xt_n == 0) return WT_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    for (int k = 0; k < h->xt_n; k++) {
+        hipEvent_t *e = &h->xt_ev[(size_t)k * 5];
+        float x = 0.0f, in = 0.0f, w = 0.0f;
+        HIP_TRY(hipEventSynchronize(e[1]));
+        HIP_TRY(hipEventSynchronize(e[4]));
+        HIP_TRY(hipEventElapsedTime(&x, e[0], e[1]));
+        HIP_TRY(hipEventElapsedTime(&in, e[2], e[3]));
+        HIP_TRY(hipEventElapsedTime(&w, e[3], e[4]));
+        h->xt_exchange_ms += x; h->xt_interior_ms += in; h->xt_exposed_ms += w;
+        h->xt_count += 1;
+    }
+    h->xt_n = 0;
+    return WT_OK;
+}
+
 extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
 {
     WT_TRY(check_handle(h));
     if (!name) return fail(WT_ERR_ARG, "option name is null");
     HIP_TRY(hipSetDevice(h->device));
+    if (strcmp(name, "agree_check") == 0) {
+        // slab handles: check that every slab of the tunnel takes the same schedule (agree_rccl / agree_local); 0 only for tests that mix on purpose
+        h->agree_check = value != 0.0;
+        h->agree_dirty = true;
+        return WT_OK;
+    }
+    if (strcmp(name, "exchange_timing") == 0) {
+        // slab handles: HIP events around every ghost exchange and the interior kernel beside it (reported by "exchange_ms", "interior_ms",
+        // "exchange_exposed_ms", "exchanges"); off by default — the events cost a few microseconds per refresh
+        h->xt_on = value != 0.0;
+        if (h->xt_on && h->xt_ev.empty()) {
+            h->xt_ev.assign((size_t)XT_RING * 5, nullptr);
+            for (hipEvent_t &e : h->xt_ev) HIP_TRY(hipEventCreate(&e));
+        }
+        h->xt_n = 0; h->xt_count = 0;
+        h->xt_exchange_ms = h->xt_interior_ms = h->xt_exposed_ms = 0.0;
+        return WT_OK;
+    }
+    h->agree_dirty = true;               // any other option may change the schedule: the next stepping call of a slab handle checks again
     if (strcmp(name, "fuse_steps") == 0) {
         if (value != 0.0 && !fuse_eligible(h))
             return fail(WT_ERR_STATE, "fuse_steps needs at least 8 local columns, a lattice below 4 GiB and (fp32) an even NY");
@@ -744,6 +848,19 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "tune_gain") == 0) { *value = h->plan_tuned ? h->tune_gain : 0.0; return WT_OK; }          // makespan modelled plan / kept plan
     if (strcmp(name, "single_steps") == 0) { *value = (double)h->single_steps; return WT_OK; }   // whole steps taken by k_step since the last init / write_f
     if (strcmp(name, "passes") == 0) { *value = (double)h->passes; return WT_OK; }
+    if (strcmp(name, "pass_depth") == 0) { *value = h->fuse_ready ? eff_depth(h) : 0; return WT_OK; }       // steps a full pass takes for the tau of the last stepping call
+    if (strcmp(name, "chain_downgrades") == 0) { *value = h->chain_downgrades; return WT_OK; }
+    if (strcmp(name, "agree_check") == 0) { *value = h->agree_check ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "agree_checks") == 0) { *value = (double)h->agree_checks; return WT_OK; }
+    if (strcmp(name, "comm_ranks") == 0) { *value = h->comm_ranks; return WT_OK; }
+    if (strcmp(name, "wave_slots") == 0) { *value = (double)h->wave_slots; return WT_OK; }
+    if (strcmp(name, "exchange_timing") == 0) { *value = h->xt_on ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "exchanges") == 0 || strcmp(name, "exchange_ms") == 0 || strcmp(name, "interior_ms") == 0 || strcmp(name, "exchange_exposed_ms") == 0) {
+        if (xt_resolve(const_cast<wt_handle *>(h)) != WT_OK) return WT_ERR_HIP;
+        *value = strcmp(name, "exchanges") == 0 ? (double)h->xt_count : strcmp(name, "exchange_ms") == 0 ? h->xt_exchange_ms
+                 : strcmp(name, "interior_ms") == 0 ? h->xt_interior_ms : h->xt_exposed_ms;
+        return WT_OK;
+    }
     if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
@@ -792,6 +909,7 @@ extern "C" int wt_set_mask(wt_handle *h, const uint8_t *mask)
     WT_TRY(classify_tiles(h->mask, h->tiles, g, h->tiles_per_col, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     h->mask_set = true;
+    h->agree_dirty = true;
     h->tune_deferred = h->masks_set > 0 && h->passes_total - h->passes_at_mask < TUNE_LIVE_PASSES;
     h->passes_at_mask = h->passes_total;
     h->masks_set += 1;
@@ -831,6 +949,8 @@ extern "C" int wt_init_equilibrium(wt_handle *h, double u0)
     h->seams_valid = false;
     h->steps_done = 0;
     h->single_steps = 0;
+    h->passes = 0;
+    h->agree_dirty = true;
     h->ghost_valid = h->halo;     // a uniform state is exact everywhere, ghosts included
     return WT_OK;
 }
@@ -959,7 +1079,12 @@ static int halo_begin(wt_handle *h)
     h->seams_valid = false;              // the refreshed ghost columns are not in the seam buffer
     HIP_TRY(hipEventRecord(h->ev_state, h->s_compute));
     HIP_TRY(hipStreamWaitEvent(h->s_comm, h->ev_state, 0));
+    if (h->xt_on) {
+        if (h->xt_n >= XT_RING) WT_TRY(xt_resolve(h));          // ring full: fold the finished refreshes into the sums (blocks on the oldest)
+        HIP_TRY(hipEventRecord(xt_event(h, 0), h->s_comm));
+    }
     if (h->transport == TR_RCCL) WT_TRY(exchange_rccl(h)); else WT_TRY(exchange_local(h));
+    if (h->xt_on) HIP_TRY(hipEventRecord(xt_event(h, 1), h->s_comm));
     HIP_TRY(hipEventRecord(h->ev_halo, h->s_comm));
     return WT_OK;
 }
@@ -981,8 +1106,11 @@ static int step_compute(wt_handle *h, double tau, double u0, bool emit, bool ref
     } else {
         const int ib = h->gl ? h->gl + 1 : 0;                     // first column whose stencil avoids the left ghosts
         const int ie = h->gr ? h->gl + h->width - 1 : g.nxl;      // one past the last such column
+        if (h->xt_on) HIP_TRY(hipEventRecord(xt_event(h, 2), h->s_compute));
         WT_TRY(launch_step_any(h, ib, ie, tau, u0, emit, h->s_compute));
+        if (h->xt_on) HIP_TRY(hipEventRecord(xt_event(h, 3), h->s_compute));
         HIP_TRY(hipStreamWaitEvent(h->s_compute, h->ev_halo, 0));
+        if (h->xt_on) { HIP_TRY(hipEventRecord(xt_event(h, 4), h->s_compute)); h->xt_n += 1; }
         if (h->gl) WT_TRY(launch_step_any(h, 0, ib, tau, u0, emit, h->s_compute));
         if (h->gr) WT_TRY(launch_step_any(h, ie, g.nxl, tau, u0, emit, h->s_compute));
         h->ghost_valid = h->halo - 1;
@@ -1051,7 +1179,7 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
     p.U0 = (T)u0;
     p.rev = (int)((h->steps_done >> 1) & 1);
     {
-        static const int rev_mode = getenv("WT_MARCH_REV") ? atoi(getenv("WT_MARCH_REV")) : 2;     // experiments: 0 / 1 = fixed order
+        static const int rev_mode = exp_env("WT_MARCH_REV") ? atoi(exp_env("WT_MARCH_REV")) : 2;     // experiments: 0 / 1 = fixed order
         if (rev_mode == 0 || rev_mode == 1) p.rev = rev_mode;
     }
     hipStream_t st = h->s_compute;
@@ -1219,9 +1347,9 @@ static int tune_fuse_plan(wt_handle *h, double tau, double u0)
     h->plan_tuned = true;
     h->tune_rounds = 0;
     h->tune_gain = 1.0;
-    static const int rounds = getenv("WT_TUNE_ROUNDS") ? atoi(getenv("WT_TUNE_ROUNDS")) : 6;
-    static const int trace = getenv("WT_TUNE_TRACE") ? atoi(getenv("WT_TUNE_TRACE")) : 0;
-    static const double damp = getenv("WT_TUNE_DAMP") ? atof(getenv("WT_TUNE_DAMP")) : 0.6;
+    static const int rounds = exp_env("WT_TUNE_ROUNDS") ? atoi(exp_env("WT_TUNE_ROUNDS")) : 6;
+    static const int trace = exp_env("WT_TUNE_TRACE") ? atoi(exp_env("WT_TUNE_TRACE")) : 0;
+    static const double damp = exp_env("WT_TUNE_DAMP") ? atof(exp_env("WT_TUNE_DAMP")) : 0.6;
     if (!h->tune || rounds <= 0 || !h->fuse_ready || h->march_depth < 3 || !plan_by_time(h) || h->n_units < 8) return WT_OK;
     const int k = fuse_pick(eff_depth(h), 1 << 20);
     if (k < 2) return WT_OK;
@@ -1342,10 +1470,126 @@ static int set_tau_cap(wt_handle *h, double tau)
     return WT_OK;
 }
 
-static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
+
+// ------------------------------------------------------------------------------------------
+// cross-rank agreement
+// ------------------------------------------------------------------------------------------
+// Everything that decides the SEQUENCE of fused passes, single steps and ghost refreshes a slab takes (run_steps, wt_plan_steps).  Over RCCL every
+// rank decides alone and the exchange is collective: two ranks that differ in any of these do not produce wrong numbers, they hang.  Inputs
+// first — so that a mismatch can be NAMED — then the outcome of the planner.  (What a rank may decide for itself is absent on purpose: the cut
+// of its units, measured or modelled, its mask columns, its device ordinal.)
+struct SchedField { const char *name; long long v; };
+static const int SCHED_FIELDS_MAX = 32;
+static long wave_slots_of(const wt_handle *h) { return h->wave_slots; }
+static int schedule_fingerprint(const wt_handle *h, SchedField *f)
+{
+    int n = 0;
+    unsigned long long eh = 1469598103934665603ULL;                  // FNV-1a over the split
+    for (int e : h->edges) { eh ^= (unsigned long long)(unsigned)e; eh *= 1099511628211ULL; }
+    auto put = [&](const char *name, long long v) { if (n < SCHED_FIELDS_MAX) { f[n].name = name; f[n].v = v; n++; } };
+    put("nx_global", h->nx_g); put("ny", h->ny); put("nranks", h->nranks); put("halo", h->halo); put("dtype", h->dtype);
+    put("edges (hash of the split)", (long long)(eh >> 1));
+    put("option fuse_steps (WT_FUSE2)", h->fuse ? (h->fuse_force ? 2 : 1) : 0);
+    put("option fuse_depth", h->fuse_depth);
+    put("option fuse_chunk (WT_FUSE_CHUNK)", h->fuse_chunk);
+    put("option chain (WT_CHAIN)", h->chain ? 1 : 0);
+    put("option fast_div (WT_FAST_DIV)", h->fast_div ? 1 : 0);
+    put("option fast_math", h->fast_math ? 1 : 0);
+    put("option plan_columns", h->plan_columns);
+    put("resident wave slots of the device (CUs x 4 SIMDs x waves)", wave_slots_of(h));
+    put("marching kernels eligible (widest slab below 4 GiB, even NY)", fuse_eligible(h) ? 1 : 0);
+    put("mask set", h->mask_set ? 1 : 0);
+    put("planner outcome: fused plan ready", h->fuse_ready ? 1 : 0);
+    put("planner outcome: steps per pass of the tables", h->fuse_ready ? h->march_depth : 0);
+    put("planner outcome: pass cap", h->fuse_ready ? h->pass_cap : 0);
+    put("state: steps done", h->steps_done);
+    put("state: exact ghost columns", h->nranks > 1 ? h->ghost_valid : 0);
+    return n;
+}
+
+static int agree_mismatch(const wt_handle *h, const SchedField &f, long long lo, long long hi, const char *when)
+{
+    return fail(WT_ERR_STATE, "slab ranks disagree on '%s' (%s): rank %d has %lld, the ranks span %lld .. %lld — every slab of a tunnel must take "
+                              "the same sequence of passes and ghost refreshes (same options, same documented WT_* environment, same split and halo "
+                              "on every rank)", f.name, when, h->rank, f.v, lo, hi);
+}
+
+// TR_RCCL: one all-reduce(max) over {v, -v} yields max and min of every field on every rank; all ranks see the same table, so all of them fail
+// together (nobody is left waiting in an exchange).  COLLECTIVE: made inside wt_comm_init_rank and at the first stepping call after a schedule
+// input changed — wt_set_option / wt_set_mask / wt_init_equilibrium / wt_write_f on a slab handle are collective in that sense (every rank
+// makes the same call), as they always had to be.
+static int agree_rccl(wt_handle *h, const char *when)
+{
+    h->agree_dirty = false;
+    if (!h->agree_check || h->transport != TR_RCCL) return WT_OK;
+    SchedField f[SCHED_FIELDS_MAX];
+    const int n = schedule_fingerprint(h, f);
+    long long host[2 * SCHED_FIELDS_MAX];
+    for (int i = 0; i < n; i++) { host[i] = f[i].v; host[n + i] = -f[i].v; }
+    if (!h->d_agree) HIP_TRY(hipMalloc((void **)&h->d_agree, 2 * SCHED_FIELDS_MAX * sizeof(long long)));
+    HIP_TRY(hipMemcpyAsync(h->d_agree, host, 2 * n * sizeof(long long), hipMemcpyHostToDevice, h->s_comm));
+    NCCL_TRY(ncclAllReduce(h->d_agree, h->d_agree, (size_t)2 * n, ncclInt64, ncclMax, h->comm, h->s_comm));
+    HIP_TRY(hipMemcpyAsync(host, h->d_agree, 2 * n * sizeof(long long), hipMemcpyDeviceToHost, h->s_comm));
+    HIP_TRY(hipStreamSynchronize(h->s_comm));
+    h->agree_checks += 1;
+    for (int i = 0; i < n; i++)
+        if (host[i] != -host[n + i]) return agree_mismatch(h, f[i], -host[n + i], host[i], when);
+    return WT_OK;
+}
+
+// TR_LOCAL: the same table compared on the host over the handles of the group.
+static int agree_local(wt_handle **hs, int n_h, const char *when)
+{
+    bool due = false, on = true;
+    for (int r = 0; r < n_h; r++) { due = due || hs[r]->agree_dirty; on = on && hs[r]->agree_check; }
+    for (int r = 0; r < n_h; r++) hs[r]->agree_dirty = false;
+    if (!due || !on || n_h < 2) return WT_OK;
+    SchedField f0[SCHED_FIELDS_MAX], fr[SCHED_FIELDS_MAX];
+    const int n = schedule_fingerprint(hs[0], f0);
+    for (int r = 1; r < n_h; r++) {
+        schedule_fingerprint(hs[r], fr);
+        for (int i = 0; i < n; i++)
+            if (fr[i].v != f0[i].v) return agree_mismatch(hs[r], fr[i], std::min(fr[i].v, f0[i].v), std::max(fr[i].v, f0[i].v), when);
+    }
+    for (int r = 0; r < n_h; r++) hs[r]->agree_checks += 1;
+    return WT_OK;
+}
+
+// The fast-division verdict decides the pass length of an fp32 four-step plan (set_tau_cap): all ranks take the kernel the LEAST lucky rank can
+// take — an all-reduce(min), the first time a tau meets a slab handle.  (The proof is deterministic arithmetic; a verdict that differs between
+// devices would be a broken device — and would otherwise show up as a hang.)
+static int agree_tau_cap_rccl(wt_handle *h, float tau)
+{
+    if (!h->agree_check || h->transport != TR_RCCL) return WT_OK;
+    if (!(h->fuse_ready && h->dtype == WT_F32 && h->march_depth == 4 && !h->fast_math)) return WT_OK;
+    if (h->fd_agreed && h->fd_agreed_tau == tau) { if (!h->fd_ok) h->tau_cap = 3; return WT_OK; }
+    long long mine = h->tau_cap == 0 ? 1 : 0, all = 0;
+    if (!h->d_agree) HIP_TRY(hipMalloc((void **)&h->d_agree, 2 * SCHED_FIELDS_MAX * sizeof(long long)));
+    HIP_TRY(hipMemcpyAsync(h->d_agree, &mine, sizeof(mine), hipMemcpyHostToDevice, h->s_comm));
+    NCCL_TRY(ncclAllReduce(h->d_agree, h->d_agree, 1, ncclInt64, ncclMin, h->comm, h->s_comm));
+    HIP_TRY(hipMemcpyAsync(&all, h->d_agree, sizeof(all), hipMemcpyDeviceToHost, h->s_comm));
+    HIP_TRY(hipStreamSynchronize(h->s_comm));
+    h->fd_agreed = true; h->fd_agreed_tau = tau;
+    if (all == 0) { h->fd_ok = false; h->tau_cap = 3; }          // somebody divides in IEEE arithmetic: so does everybody
+    return WT_OK;
+}
+
+// What a stepping call does before its first launch: the pass cap of this tau, the cross-rank checks that are due, the measured cut of a new plan.
+// (wt_step_timed runs it BEFORE its first event: the 13 trial passes of a new plan are not step time — ADVICE r3.)
+static int prepare_steps(wt_handle *h, int nsteps, double tau, double u0)
 {
     WT_TRY(set_tau_cap(h, tau));
+    if (h->transport == TR_RCCL) {
+        if (h->agree_dirty) WT_TRY(agree_rccl(h, "first stepping call after a change"));
+        WT_TRY(agree_tau_cap_rccl(h, (float)tau));
+    }
     if (tune_due(h, nsteps)) WT_TRY(tune_fuse_plan(h, tau, u0));
+    return WT_OK;
+}
+
+static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
+{
+    WT_TRY(prepare_steps(h, nsteps, tau, u0));
     int s = 0;
     while (s < nsteps) {
         const int k = fuse_stride(h, nsteps - s);
@@ -1406,6 +1650,7 @@ extern "C" int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, fl
     if (!elapsed_ms) return fail(WT_ERR_ARG, "elapsed_ms is null");
     if (h->transport == TR_LOCAL) return fail(WT_ERR_STATE, "locally linked slabs are stepped with wt_step_group");
     HIP_TRY(hipSetDevice(h->device));
+    WT_TRY(prepare_steps(h, nsteps, tau, u0));          // (the trial passes of a new plan are not step time)
     HIP_TRY(hipEventRecord(h->ev_a, h->s_compute));
     WT_TRY(run_steps(h, nsteps, tau, u0));
     HIP_TRY(hipEventRecord(h->ev_b, h->s_compute));
@@ -1439,7 +1684,10 @@ extern "C" int wt_comm_init_rank(wt_handle *h, const void *id_in)
     memcpy(&id, id_in, sizeof(id));
     NCCL_TRY(ncclCommInitRank(&h->comm, h->nranks, id, h->rank));
     h->transport = TR_RCCL;
-    return WT_OK;
+    NCCL_TRY(ncclCommCount(h->comm, &h->comm_ranks));
+    if (h->comm_ranks != h->nranks) return fail(WT_ERR_RCCL, "the communicator holds %d ranks, the tunnel has %d slabs", h->comm_ranks, h->nranks);
+    // every rank proves, before the first exchange, that it will take the schedule its neighbours take
+    return agree_rccl(h, "wt_comm_init_rank");
 }
 
 // RCCL plumbing check on ONE GPU: a one-rank communicator, then the same grouped
@@ -1516,6 +1764,20 @@ extern "C" int wt_link_local(wt_handle **hs, int n)
     return WT_OK;
 }
 
+static int group_prepare(wt_handle **hs, int n, int nsteps, double tau, double u0)
+{
+    for (int r = 0; r < n; r++) {
+        HIP_TRY(hipSetDevice(hs[r]->device));
+        WT_TRY(set_tau_cap(hs[r], tau));
+    }
+    WT_TRY(agree_local(hs, n, "wt_step_group"));
+    for (int r = 0; r < n; r++) {
+        HIP_TRY(hipSetDevice(hs[r]->device));
+        if (tune_due(hs[r], nsteps)) WT_TRY(tune_fuse_plan(hs[r], tau, u0));
+    }
+    return WT_OK;
+}
+
 extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, double u0)
 {
     if (!hs || n < 1) return fail(WT_ERR_ARG, "no handles");
@@ -1524,11 +1786,7 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
         if (n > 1 && hs[r]->transport != TR_LOCAL) return fail(WT_ERR_STATE, "handle %d is not locally linked", r);
         if (hs[r]->steps_done != hs[0]->steps_done) return fail(WT_ERR_STATE, "slabs are not at the same step");
     }
-    for (int r = 0; r < n; r++) {
-        HIP_TRY(hipSetDevice(hs[r]->device));
-        WT_TRY(set_tau_cap(hs[r], tau));
-        if (tune_due(hs[r], nsteps)) WT_TRY(tune_fuse_plan(hs[r], tau, u0));
-    }
+    WT_TRY(group_prepare(hs, n, nsteps, tau, u0));
     int s = 0;
     while (s < nsteps) {
         // one pass length for the whole group: the shortest plan depth and the fewest exact ghost columns of any slab (edge
@@ -1593,8 +1851,9 @@ extern "C" int wt_step_group_timed(wt_handle **hs, int n, int nsteps, double tau
 {
     if (!hs || n < 1) return fail(WT_ERR_ARG, "no handles");
     if (!elapsed_ms) return fail(WT_ERR_ARG, "elapsed_ms is null");
+    for (int r = 0; r < n; r++) WT_TRY(check_steppable(hs[r], nsteps, tau, u0));
+    WT_TRY(group_prepare(hs, n, nsteps, tau, u0));          // (the trial passes of a new plan are not step time)
     for (int r = 0; r < n; r++) {
-        WT_TRY(check_handle(hs[r]));
         HIP_TRY(hipSetDevice(hs[r]->device));
         HIP_TRY(hipEventRecord(hs[r]->ev_a, hs[r]->s_compute));
     }
@@ -1681,6 +1940,8 @@ extern "C" int wt_write_f(wt_handle *h, const void *f_in)
     h->ghost_valid = 0;      // ghosts must be refreshed from the neighbours before the next step
     h->steps_done = 0;
     h->single_steps = 0;
+    h->passes = 0;
+    h->agree_dirty = true;
     return WT_OK;
 }
 

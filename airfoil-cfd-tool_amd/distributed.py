@@ -31,6 +31,17 @@ def slab_bounds(nx: int, nranks: int, edges: Optional[List[int]] = None) -> List
     return [(edges[r], edges[r + 1] - edges[r]) for r in range(nranks)]
 
 
+DEFAULT_HALO = 17       # ghost columns per interior side: one refresh step + four four-step passes between two exchanges
+
+
+def default_halo(bounds: List[Tuple[int, int]], halo: Optional[int] = None) -> int:
+    """The hosts' halo depth: `halo` as given; None = DEFAULT_HALO clamped to the narrowest slab of the split (a halo cannot be deeper than
+    the columns the neighbour owns — wt_create_slab refuses that, and an EXPLICIT value that is too deep still fails there, loudly)."""
+    if halo is not None:
+        return int(halo)
+    return max(1, min(DEFAULT_HALO, min(w for _, w in bounds)))
+
+
 def balanced_edges(edges: List[int], cost: List[float], min_width: int) -> List[int]:
     """One round of cutting the slabs by cost instead of by width.  `cost[r]` is what slab r of the split `edges` was measured to take per
     step (any unit): the cost is spread evenly over the slab's columns, and the new edges cut the running cost into equal parts.
@@ -140,7 +151,7 @@ class SlabWindTunnel(WindTunnel):
     """The :class:`WindTunnel` surface for a lattice sharded over the ranks of a process group.
     Every method is collective: all ranks call it with the same arguments."""
 
-    def __init__(self, coords=None, name: str = "", *, halo: int = 17, device: Optional[int] = None, group=None,
+    def __init__(self, coords=None, name: str = "", *, halo: Optional[int] = None, device: Optional[int] = None, group=None,
                  engine_factory: Callable = _default_engine_factory, nx: int = 4096, ny: int = 2048, edges: Optional[List[int]] = None,
                  **kwargs):
         """edges: the split (nranks + 1 rising column indices, the same on every rank; see balanced_edges), None for equal widths."""
@@ -154,7 +165,7 @@ class SlabWindTunnel(WindTunnel):
         self.edges = None if edges is None else [int(e) for e in edges]
         self.bounds = slab_bounds(int(nx), self.nranks, self.edges)
         self.x0, self.width = self.bounds[self.rank]
-        self.halo = int(halo) if self.nranks > 1 else 0
+        self.halo = default_halo(self.bounds, halo) if self.nranks > 1 else 0
         self._engine_factory = engine_factory
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -323,10 +334,10 @@ class LocalSlabWindTunnel(WindTunnel):
     """:class:`WindTunnel` over several GPUs driven by ONE process (no torch.distributed, no RCCL):
     ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=17, nx=8192, ny=4096)``."""
 
-    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: int = 17, edges=None, **kwargs):
+    def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: Optional[int] = None, edges=None, **kwargs):
         self.devices = [int(d) for d in devices]
-        self.halo = int(halo)
         self.edges = None if edges is None else [int(e) for e in edges]
+        self.halo = default_halo(slab_bounds(int(kwargs.get("nx", 320)), max(1, len(self.devices)), self.edges), halo)
         if len(self.devices) < 2:
             raise ValueError("LocalSlabWindTunnel needs at least two slabs; use WindTunnel for one GPU")
         super().__init__(coords, name, device=self.devices[0], **kwargs)

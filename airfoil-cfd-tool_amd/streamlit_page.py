@@ -32,6 +32,22 @@ from .windtunnel import WindTunnel
 _FIELD_LABELS = {"Velocity": "speed", "Pressure (Cp)": "cp", "Vorticity": "vort"}     # html:32-36
 
 
+def _full_width_kwarg(image_fn) -> dict:
+    """The keyword that stretches an image over its column: `use_container_width` where the installed Streamlit has it (1.40+; the older
+    `use_column_width` is deprecated there), else `use_column_width` — the same sizing AA.py:42's `components.html(..., height=680)` gives the
+    iframe.  Decided from the signature of the placeholder's own `image`, so that no Streamlit version is assumed."""
+    import inspect
+    try:
+        params = inspect.signature(image_fn).parameters
+    except (TypeError, ValueError):
+        return {}
+    if "use_container_width" in params:
+        return {"use_container_width": True}
+    if "use_column_width" in params:
+        return {"use_column_width": True}
+    return {}
+
+
 def _tunnel_for(st, coords_after, airfoil_name: str, nx: int, ny: int, dtype: str) -> WindTunnel:
     """One tunnel per (coordinates, lattice) in the session, like the iframe's one GL context."""
     key = ("wt_amd", hash(tuple((round(float(x), 6), round(float(y), 6)) for x, y in coords_after)), nx, ny, dtype)
@@ -89,7 +105,7 @@ def build_lbm_component(coords_after, airfoil_name: str = "", *, nx: int = 1024,
             tracers.draw(layer, 16.0)                                                # stepParticles(dt), html:917
         st.session_state["wt_amd_frames"] = st.session_state.get("wt_amd_frames", 0) + max(1, int(frames_per_update))
         canvas.image(wt.compose_frame(trails=layer, scale=scale), caption="D2Q9 lattice-Boltzmann · MI355X · live unsteady solve",
-                     use_column_width=True)
+                     **_full_width_kwarg(canvas.image))
         s = wt.stats()                                                               # updateStatsUI, html:862-885
         slots[0].metric("CL (approx)", "—" if s.cl is None else f"{s.cl:.3f}")
         slots[1].metric("CD (approx)", "—" if s.cd is None else f"{s.cd:.3f}")

@@ -29,6 +29,13 @@
 #include <stdint.h>
 #include <stddef.h>
 
+/* The library is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols. */
+#if defined(__GNUC__)
+#define WT_API __attribute__((visibility("default")))
+#else
+#define WT_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -68,13 +75,13 @@ typedef struct wt_info {
 
 /* Replaces the WebGL context + texture/FBO creation (html:87-95, 438-469, 492-500).
  * One handle = the whole NX x NY lattice on one GPU. */
-int wt_create(int nx, int ny, int dtype, int device, wt_handle **out);
+WT_API int wt_create(int nx, int ny, int dtype, int device, wt_handle **out);
 
 /* One column slab of a lattice that is split over `nranks` handles (one GPU
  * each): rank r owns global columns [r*NX/nranks, (r+1)*NX/nranks) plus `halo`
  * ghost columns on each interior side, refreshed every `halo` steps.  New design
  * (the reference is single-context); SURVEY.md §8e. */
-int wt_create_slab(int nx_global, int ny, int dtype, int device,
+WT_API int wt_create_slab(int nx_global, int ny, int dtype, int device,
                    int rank, int nranks, int halo, wt_handle **out);
 
 /* The same with the split given by the caller: edges[0] = 0 < edges[1] < ... <
@@ -82,13 +89,13 @@ int wt_create_slab(int nx_global, int ny, int dtype, int device,
  * passes the SAME array (the narrowest slab decides the steps per pass of all
  * of them).  For tunnels whose body makes some columns dearer than others:
  * the host cuts the slabs by measured cost (distributed.balanced_edges). */
-int wt_create_slab_at(int nx_global, int ny, int dtype, int device,
+WT_API int wt_create_slab_at(int nx_global, int ny, int dtype, int device,
                       int rank, int nranks, int halo, const int *edges, wt_handle **out);
 
-int wt_destroy(wt_handle *h);
-int wt_get_info(const wt_handle *h, wt_info *info);
-const char *wt_last_error(void);
-const char *wt_version(void);
+WT_API int wt_destroy(wt_handle *h);
+WT_API int wt_get_info(const wt_handle *h, wt_info *info);
+WT_API const char *wt_last_error(void);
+WT_API const char *wt_version(void);
 
 /* Tuning knobs (no counterpart in the reference).  Every setting but "fast_math" gives bit-identical results.
  *   "fuse_steps" (0 / 1 = where it pays / 2 = always): advance SEVERAL steps per pass over the lattice — marching kernels that keep
@@ -121,10 +128,31 @@ const char *wt_version(void);
  *       multiply-adds, v_rcp / v_rsq for the divisions and the square root (csrc/d2q9.hpp collide_contracted).  Held to BASELINE.md's
  *       tolerance against the oracle (|d rho| <= 1e-5, |d u| <= 5e-6; tests/test_gpu_fast_math.py), +19 % on 4096^2, +36 % on a
  *       544-column slab.  k_step (single steps, HBM-bound) keeps the reference arithmetic.
- * wt_get_option also reports "fuse_active", "fuse_units", "chain_units", "fuse_depth" / "fuse_sites" (in use), "fuse_tiles_general",
- * "fast_div_active", "tune_rounds", "tune_gain", "passes" and "single_steps" (fused passes / whole k_step steps since the last init or wt_write_f). */
-int wt_set_option(wt_handle *h, const char *name, double value);
-int wt_get_option(const wt_handle *h, const char *name, double *value);
+ *   "agree_check" (default 1, slab handles): every slab of a tunnel must take the SAME sequence of fused passes, single steps and ghost
+ *       refreshes — over RCCL each rank decides alone and the exchange is collective, so a rank that decides differently is a hang.  The
+ *       library therefore compares, across the slabs, everything that decides that sequence (lattice, split, halo, dtype, the options above,
+ *       the documented WT_* environment presets, the device's resident wave slots, the planner's outcome): by an all-reduce inside
+ *       wt_comm_init_rank and again at the first stepping call after wt_set_option / wt_set_mask / wt_init_equilibrium / wt_write_f (which
+ *       are collective on slab handles: every rank makes the same call), by a host comparison in wt_step_group; a mismatch fails with
+ *       WT_ERR_STATE naming the field and both values.  The fast-division verdict for a tau is agreed the same way (all-reduce(min)).
+ *       0 is for tests that mix plans on purpose.  "agree_checks" counts the checks made.
+ *   "exchange_timing" (default 0, slab handles): HIP events around every ghost exchange (comm stream) and around the interior kernel and the
+ *       wait that follows it (compute stream); summed over the refresh steps since the option was set by "exchange_ms", "interior_ms",
+ *       "exchange_exposed_ms" (what the compute stream still waited after its interior kernel) and counted by "exchanges".
+ * wt_get_option also reports "fuse_active", "fuse_units", "chain_units", "fuse_depth" (steps per pass the plan's tables are built for) /
+ * "pass_depth" (steps a full pass takes for the tau of the last stepping call: 3 on a four-step fp32 plan whose tau has no proved fast
+ * division) / "fuse_sites" (in use), "fuse_tiles_general", "fast_div_active", "tune_rounds", "tune_gain", "chain_downgrades" (groups of four
+ * units whose chain flags failed the library's plan check and were downgraded to solo units: 0 by construction), "comm_ranks" (ncclCommCount of
+ * the handle's communicator), "wave_slots", "passes" and "single_steps" (fused passes / whole k_step steps since the last
+ * wt_init_equilibrium or wt_write_f).
+ *
+ * Environment.  Five variables preset a handle's options at wt_create and are part of the interface (and of the cross-rank check above):
+ *   WT_FUSE2=0|1|2 ("fuse_steps"), WT_FUSE_CHUNK=n ("fuse_chunk"), WT_FAST_DIV=0|1 ("fast_div"), WT_CHAIN=0|1 ("chain"), WT_TUNE=0|1 ("tune").
+ * Nothing else in the environment reaches a production library.  The planner constants and launch orders the experiments under tools/ vary
+ * (WT_PLAN_TIMED, WT_ALPHA, WT_ALPHA_SOLID, WT_BETA, WT_MAX_CHAIN, WT_MARCH_WAVES, WT_MARCH_ROUNDS, WT_MARCH_REV, WT_DEPTH3_MIN, WT_DEPTH4_MIN,
+ * WT_TUNE_ROUNDS, WT_TUNE_DAMP, WT_TUNE_TRACE) are read only by a library built with -DWT_EXPERIMENT_KNOBS (`make lib EXPERIMENT=1`). */
+WT_API int wt_set_option(wt_handle *h, const char *name, double value);
+WT_API int wt_get_option(const wt_handle *h, const char *name, double *value);
 
 /* ---- ghost-column transport for slab handles -------------------------------- */
 
@@ -132,21 +160,21 @@ int wt_get_option(const wt_handle *h, const char *name, double *value);
  * broadcasts the WT_COMM_ID_BYTES bytes (e.g. torch.distributed), then EVERY
  * rank calls wt_comm_init_rank (collective). */
 #define WT_COMM_ID_BYTES 128
-int wt_comm_unique_id(void *id_out);
-int wt_comm_init_rank(wt_handle *h, const void *id);
+WT_API int wt_comm_unique_id(void *id_out);
+WT_API int wt_comm_init_rank(wt_handle *h, const void *id);
 /* One-GPU check of the RCCL plumbing: one-rank communicator + the grouped send/recv pattern of the
  * ghost exchange (to self).  0 on success. */
-int wt_comm_selftest(int device, int ny);
+WT_API int wt_comm_selftest(int device, int ny);
 
 /* In-process transport: all slabs of one tunnel live in the calling process
  * (any mix of devices); ghost columns move by peer copies.  `hs` are the
  * nranks slab handles ordered by rank.  Stepping then goes through
  * wt_step_group, which advances every slab in lock-step. */
-int wt_link_local(wt_handle **hs, int n);
-int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, double u0);
+WT_API int wt_link_local(wt_handle **hs, int n);
+WT_API int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, double u0);
 /* As wt_step_group, every slab's share bracketed by HIP events on that slab's compute stream; blocks, and returns the
  * elapsed device time of each slab in milliseconds (elapsed_ms[n]).  Measurement only (bench.py --local-slabs). */
-int wt_step_group_timed(wt_handle **hs, int n, int nsteps, double tau, double u0, float *elapsed_ms);
+WT_API int wt_step_group_timed(wt_handle **hs, int n, int nsteps, double tau, double u0, float *elapsed_ms);
 
 /* ---- state ------------------------------------------------------------------ */
 
@@ -154,28 +182,28 @@ int wt_step_group_timed(wt_handle **hs, int n, int nsteps, double tau, double u0
  * `mask` is the WHOLE tunnel's mask, [NY][NX_global] uint8, non-zero = solid;
  * a slab handle takes the columns it needs (owned + ghost).  The flow state is
  * NOT re-initialised (html:579-586). */
-int wt_set_mask(wt_handle *h, const uint8_t *mask);
+WT_API int wt_set_mask(wt_handle *h, const uint8_t *mask);
 
 /* Replaces initSim/equilibriumInitData (html:474-500): every site, solids
  * included, gets feq(rho=1,u=(u0,0)) evaluated in double and stored in the
  * handle's dtype; macro = (1,u0,0). */
-int wt_init_equilibrium(wt_handle *h, double u0);
+WT_API int wt_init_equilibrium(wt_handle *h, double u0);
 
 /* Replaces `nsteps` x simStep (html:510-525) = STEP_FS main() (html:283-360) per
  * site: pull-stream, half-way bounce-back, far-field/outlet BC, moments, clamp,
  * BGK.  tau and u0 are the shader uniforms (html:521-522), converted to the
  * handle's dtype.  The LAST step of the call also stores the macroscopic
  * fields (rho,ux,uy) that the reference writes into texC (html:357-359). */
-int wt_step(wt_handle *h, int nsteps, double tau, double u0);
+WT_API int wt_step(wt_handle *h, int nsteps, double tau, double u0);
 
 /* How `nsteps` steps would be taken from the handle's present state, without taking them: seq[i] = +k for a fused pass of k steps, 1 for a
  * single step, -1 for a single step that refreshes the ghost columns first; returns the length of the sequence (at most `cap` entries are
  * written).  Slab handles of one tunnel answer alike — the property the collective exchange over RCCL rests on. */
-int wt_plan_steps(wt_handle *h, int nsteps, double tau, int *seq, int cap);
+WT_API int wt_plan_steps(wt_handle *h, int nsteps, double tau, int *seq, int cap);
 
 /* As wt_step, bracketed by HIP events on the stream the step kernels run on;
  * blocks, and returns the elapsed device time in milliseconds. */
-int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, float *elapsed_ms);
+WT_API int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, float *elapsed_ms);
 
 /* Test / checkpoint access to the populations, [9][NY][W].
  * wt_write_f replaces the populations only: the (rho,ux,uy) planes the reference keeps in texC are the pre-collision
@@ -183,42 +211,42 @@ int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, float *elapse
  * wt_write_f the calls that read them (wt_read_macro, wt_reduce_ranges, wt_forces, wt_field, wt_render_rgba,
  * wt_advect_tracers) return WT_ERR_STATE until a wt_step / wt_step_group with nsteps >= 1 has emitted them again.
  * Slab handles: ghost columns are refreshed from the neighbours before the next step. */
-int wt_read_f(wt_handle *h, void *f_out);
-int wt_write_f(wt_handle *h, const void *f_in);
+WT_API int wt_read_f(wt_handle *h, void *f_out);
+WT_API int wt_write_f(wt_handle *h, const void *f_in);
 
 /* ---- read-backs and reductions ---------------------------------------------- */
 
 /* Replaces readMacro (html:547-552): rho, ux, uy of the last step, each [NY][W]. */
-int wt_read_macro(wt_handle *h, void *rho, void *ux, void *uy);
+WT_API int wt_read_macro(wt_handle *h, void *rho, void *ux, void *uy);
 
 /* Replaces the range scan of updateFieldsFromMacro (html:596-614), in doubles
  * over fluid sites: max_s = max hypot(ux,uy)/u0 over values < 4 (0 if none);
  * cp range over -4 < cp < 1.2 with cp=(rho-1)/(1.5 u0^2) (+inf/-inf if none).
  * Partial result of the handle's owned columns; the "keep the previous value"
  * rule (html:611-613) stays with the caller, as in the page. */
-int wt_reduce_ranges(wt_handle *h, double u0, double *max_s, double *cp_min, double *cp_max);
+WT_API int wt_reduce_ranges(wt_handle *h, double u0, double *max_s, double *cp_min, double *cp_max);
 
 /* Replaces computeForces' two scans (html:650-698), raw sums over the fluid/
  * solid faces whose FLUID cell is owned: fx,fy = sum of (rho_fluid/3) * (unit
  * vector from the fluid cell into the solid); surf = face count; rev = faces
  * whose fluid cell has ux < 0.  Coefficients and smoothing stay with the caller
  * (html:676-679, 699). */
-int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, int64_t *rev);
+WT_API int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, int64_t *rev);
 
 /* Diagnostics of the stability net STEP_FS applies silently (html:344-350; SURVEY §5 "clamp-event counter"): the number
  * of owned fluid sites whose last emitted state sits at a density bound (rho = 0.5 or 2.0) and at the speed bound
  * (|u| = 0.35).  Both are 0 in a healthy run.  Per-slab partials, like wt_forces. */
-int wt_clamp_events(wt_handle *h, int64_t *rho_events, int64_t *u_events);
+WT_API int wt_clamp_events(wt_handle *h, int64_t *rho_events, int64_t *u_events);
 
 /* Replaces RENDER_FS main()'s field math (html:395-420): the scalar t handed to
  * the colour map, [NY][W], NaN on solid sites.  max_s/cp_min/cp_max are the
  * uniforms of html:540-542, vort_scale html:528/543. */
-int wt_field(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
+WT_API int wt_field(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
              double vort_scale, void *t_out);
 
 /* Replaces RENDER_FS's colour maps (html:371-393, 397): RGBA8 image, [NY][W][4],
  * row 0 = bottom. */
-int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
+WT_API int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
                    double vort_scale, uint8_t *rgba_out);
 
 /* Replaces advect() (html:758-771) over sampleUV/sampleScalar (html:616-639) for n tracer
@@ -226,11 +254,11 @@ int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, double cp_mi
  * (bilinear over fluid cells only).  dt_frame is the frame time in ms (html:903); the window is
  * html:73's DX0,DX1,DY0,DY1.  ok[i]=0 where the reference returns null (outside the window or no
  * fluid sample): x_new/y_new then repeat the input.  Whole-lattice handles only. */
-int wt_advect_tracers(wt_handle *h, int n, const double *x, const double *y, double dt_frame, double u0,
+WT_API int wt_advect_tracers(wt_handle *h, int n, const double *x, const double *y, double dt_frame, double u0,
                       double dx0, double dx1, double dy0, double dy1,
                       double *x_new, double *y_new, double *speed, uint8_t *ok);
 
-int wt_sync(wt_handle *h);
+WT_API int wt_sync(wt_handle *h);
 
 #ifdef __cplusplus
 }

@@ -84,9 +84,68 @@ static int check(const char *name, int nxl, int ny, int gi0, int nx_g, int win, 
     return bad;
 }
 
+// The library checks every plan it uploads (sanitize_chain_plan, step_chain.hpp): a group of four units that carries chain flags without being a
+// well-formed chain block must come out as solo units — never reach the kernel, whose LDS hand-over would spin on it.  Corrupt a good plan in
+// the ways a planner bug could, and look at what the guard hands on.
+static int check_sanitize(int depth, int corruption, unsigned seed)
+{
+    Geom g{};
+    const int nxl = 544, ny = 4096, gi0 = 1760, nx_g = 4096, win = 128;
+    g.nxl = nxl; g.ny = ny; g.gi0 = gi0; g.nx_g = nx_g; g.pitch = (ny + 255) / 256 * 256; g.plane = (long)(nxl + 2) * g.pitch + 4352;
+    const int nwin = march_nwin(ny, win), ld = nxl + 2;
+    std::vector<uint8_t> wcls((size_t)nwin * ld, WC_FAST);
+    std::mt19937 rng(seed);
+    for (int w = 0; w < nwin; w++)
+        for (int x = 0; x < nxl; x++)
+            if ((w % 3 == 1) && x > nxl / 3 && x < nxl / 2 && rng() % 1000 < 600) wcls[(size_t)w * ld + x + 1] = WC_GENERAL;
+    const MarchRange r = march_range3(g, depth);
+    const int min_last = depth == 4 ? 2 : 1, max_len = depth == 4 ? MARCH3_MAX_CHUNK - 3 : MARCH3_MAX_CHUNK;
+    const double over = depth == 4 ? 4.5 : 2.7, tail = depth == 4 ? 1.25 : 1.0;
+    const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, 1.25, 0.6, 160, 0.3};
+    // (a small target: long chain units, so that a downgraded one has to be split for the solo kernel's class masks)
+    MarchPlan pl = build_chain_plan_timed(wcls.data(), g, win, corruption == 5 ? 192 : 2048, 2.2, r, min_last, max_len, depth, cc, nullptr);
+    MarchPlan good = pl;
+    int bad = 0;
+    if (sanitize_chain_plan(good, wcls.data(), g, depth, max_len - 2) != 0 || good.units.size() != pl.units.size()) { printf("sanitize touched a good plan\n"); bad++; }
+    std::vector<size_t> chain_groups;
+    for (size_t b = 0; b + 3 < pl.units.size(); b += 4) if (pl.units[b].flags & MU_CHAIN) chain_groups.push_back(b);
+    if (chain_groups.empty()) { printf("no chain block to corrupt\n"); return 1; }
+    const size_t b = chain_groups[rng() % chain_groups.size()];
+    MarchUnit *u = &pl.units[b];
+    switch (corruption) {
+    case 0: u[2].flags &= ~MU_CHAIN; break;                                   // three chain units and a solo one: the barrier would not be uniform
+    case 1: u[1].ib -= (u[1].ib - u[1].ia) - depth; u[2].ia = u[1].ib; break;  // a chain unit shorter than the pipeline (depth columns)
+    case 2: std::swap(u[1], u[2]); break;                                     // partners that are not neighbours
+    case 3: u[0].flags = MU_CHAIN; break;                                     // wrong direction flag
+    case 4: wcls[(size_t)u[0].w * ld + u[1].ia + 1] = WC_GENERAL; break;       // a body column inside the footprint
+    case 5: u[3].flags |= MU_CHAIN | MU_END_SHARED; break;                     // (long units) an end seam nobody shares
+    }
+    if (corruption == 1 && u[2].ib - u[2].ia > 160) return 0;
+    const int nd = sanitize_chain_plan(pl, wcls.data(), g, depth, max_len - 2);
+    if (nd < 1) { printf("corruption %d (depth %d) not detected\n", corruption, depth); bad++; }
+    if (pl.units.size() % 4) bad++;
+    std::vector<int> cover((size_t)nwin * nxl, 0);
+    for (size_t q = 0; q + 3 < pl.units.size(); q += 4) {
+        int nc = 0;
+        for (int k = 0; k < 4; k++) nc += (pl.units[q + k].flags & (MU_CHAIN | MU_DIR_NEG | MU_END_SHARED)) != 0;
+        if (nc && !chain_group_ok(&pl.units[q], wcls.data(), g, depth)) { printf("an ill-formed chain group survived\n"); bad++; }
+    }
+    for (const MarchUnit &x : pl.units) {
+        if (x.ib <= x.ia) continue;
+        if (!(x.flags & MU_CHAIN) && x.ib - x.ia > max_len) bad++;
+        for (int c = x.ia; c < x.ib; c++) cover[(size_t)x.w * nxl + c]++;
+    }
+    for (int w = 0; w < nwin; w++)
+        for (int x = 0; x < nxl; x++) if (cover[(size_t)w * nxl + x] != ((x >= r.i_begin && x < r.i_end) ? 1 : 0)) { bad++; break; }
+    printf("sanitize: depth %d corruption %d -> %d group(s) downgraded, %zu units  %s\n", depth, corruption, nd, pl.units.size(), bad ? "FAIL" : "ok");
+    return bad;
+}
+
 int main()
 {
     int bad = 0;
+    for (int depth : {3, 4})
+        for (int c = 0; c < 6; c++) bad += check_sanitize(depth, c, 100u + (unsigned)(10 * depth + c));
     for (int depth : {2, 3, 4}) {
         const int win = depth == 2 ? 256 : 128;
         bad += check("whole lattice", 4096, 4096, 0, 4096, win, depth, 4096, 0, 1);

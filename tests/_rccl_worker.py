@@ -31,8 +31,17 @@ def main():
         eng.set_option("fuse_steps", 2)
         ids = [pkg.Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        eng.comm_init_rank(ids[0])
+        eng.comm_init_rank(ids[0])                          # (all-reduces the schedule fingerprint: a rank that would plan differently fails here)
+        assert int(eng.get_option("comm_ranks")) == world
         eng.set_mask(mask); eng.init_equilibrium(0.06)
+        # before the first exchange: every rank answers wt_plan_steps alike (the property the collective exchange rests on)
+        plans = [None] * world
+        dist.all_gather_object(plans, (eng.get_option("fuse_active"), eng.get_option("fuse_depth"), tuple(eng.plan_steps(sum(chunks), 0.58))))
+        if len(set(plans)) != 1:
+            print(f"rank {rank}: the ranks plan different schedules: {plans}", flush=True)
+            ok = False
+            eng.close()
+            break
         for n in chunks:
             eng.step(n, 0.58, 0.06)
         f = eng.read_f()                                    # this rank's owned columns
@@ -53,6 +62,22 @@ def main():
                             for i, m in ((1, r0), (2, u0), (3, v0))))
             print(f"rccl slabs {dtype} depth={depth or 'auto'} world={world} edges={edges or 'equal'}: {'PASS' if same else 'FAIL'}", flush=True)
             ok &= bool(same)
+    # a rank with another knob value is refused by EVERY rank inside wt_comm_init_rank — an error, not a hang at the first exchange
+    eng = pkg.Engine(nx, ny, device=local, rank=rank, nranks=world, halo=halo)
+    eng.set_option("fuse_depth", 3 if rank == world - 1 else 4)
+    ids = [pkg.Engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    refused = False
+    try:
+        eng.comm_init_rank(ids[0])
+    except pkg.WTError as e:
+        refused = e.code == -5 and "disagree" in str(e) and "fuse_depth" in str(e)
+    eng.close()
+    got = [None] * world
+    dist.all_gather_object(got, refused)
+    if rank == 0:
+        print(f"rccl slabs: a rank with another fuse_depth is refused on every rank: {'PASS' if all(got) else 'FAIL'}", flush=True)
+    ok &= all(got)
     flag = torch.tensor([1 if ok else 0], device=torch.device("cuda", local))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.barrier()

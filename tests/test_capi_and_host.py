@@ -28,6 +28,29 @@ def test_library_exports_every_declared_symbol(pkg):
     assert b"libwindtunnel" in lib.wt_version()
 
 
+def test_dynamic_symbol_table_is_the_header(pkg):
+    """Built with -fvisibility=hidden and a version script (csrc/libwindtunnel.map): the library's dynamic symbols are exactly the entry
+    points include/windtunnel.h declares — no kernel stubs, no libstdc++ instantiations, no C++ internals."""
+    import subprocess
+    from airfoil_cfd_tool_amd._capi import LIB_PATH
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], check=True, capture_output=True, text=True).stdout
+    syms = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert syms == _declared_exports(), sorted(set(syms) ^ set(_declared_exports()))
+    assert len(syms) == 30
+
+
+def test_streamlit_image_keyword_follows_the_installed_version():
+    """streamlit_page._full_width_kwarg: `use_container_width` where Streamlit's image() has it, the older keyword otherwise."""
+    from airfoil_cfd_tool_amd.streamlit_page import _full_width_kwarg
+
+    def new(img, caption=None, use_column_width=None, use_container_width=False): ...
+    def old(img, caption=None, use_column_width=None): ...
+    def bare(img): ...
+    assert _full_width_kwarg(new) == {"use_container_width": True}
+    assert _full_width_kwarg(old) == {"use_column_width": True}
+    assert _full_width_kwarg(bare) == {}
+
+
 def test_argument_errors_without_a_gpu(pkg):
     lib = pkg.load_library()
     h = ctypes.c_void_p()

@@ -335,6 +335,8 @@ def test_slabs_choose_one_plan_depth_and_mixed_groups_still_take_fused_passes(pk
         try:
             pkg.Engine.link_local(es)
             for r, e in enumerate(es):
+                if forced:
+                    e.set_option("agree_check", 0)       # mixed on purpose: the library would otherwise refuse the group (test_gpu_slabs.py)
                 if forced and 0 < r < nranks - 1:
                     e.set_option("fuse_depth", 4)
                 e.set_mask(mask); e.init_equilibrium(0.06)

@@ -264,3 +264,101 @@ def test_the_planned_schedule_is_the_one_that_runs(pkg):
     finally:
         for e in es:
             e.close()
+
+
+def test_slabs_that_would_take_different_schedules_are_refused(pkg):
+    """Rank agreement is a checked property: two locally linked slabs with deliberately different knob values get
+    WT_ERR_STATE naming the field at their first stepping call — not a divergent plan (over RCCL: a hang).  The same table is all-reduced
+    inside wt_comm_init_rank and at the first wt_step after a change on the RCCL transport (tests/_rccl_worker.py)."""
+    nx, ny, nranks, halo = 2400, 1024, 2, 16
+    mask = pkg.geometry.build_geometry(nx, ny, 7.0, None, "naca2412").mask
+    for knob, v0, v1, needle in (("fuse_depth", 4, 3, "fuse_depth"), ("fast_div", 1, 0, "fast_div"), ("chain", 1, 0, "chain"),
+                                 ("fuse_steps", 2, 0, "fuse_steps"), ("plan_columns", 0, 300, "plan_columns")):
+        es = [pkg.Engine(nx, ny, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+        try:
+            pkg.Engine.link_local(es)
+            es[0].set_option(knob, v0); es[1].set_option(knob, v1)
+            for e in es:
+                e.set_mask(mask); e.init_equilibrium(0.06)
+            with pytest.raises(pkg.WTError) as ei:
+                pkg.Engine.step_group(es, 20, 0.58, 0.06)
+            assert ei.value.code == -5 and "disagree" in str(ei.value) and needle in str(ei.value), str(ei.value)
+            assert all(e.info().steps_done == 0 for e in es)                      # refused before anything ran
+            es[1].set_option(knob, v0)                                            # put right: the next call checks again and runs
+            pkg.Engine.step_group(es, 20, 0.58, 0.06)
+            assert all(e.info().steps_done == 20 and e.get_option("agree_checks") >= 1 for e in es)
+        finally:
+            for e in es:
+                e.close()
+    # a halo that differs is caught when the group is linked, as before
+    es = [pkg.Engine(nx, ny, rank=0, nranks=2, halo=16), pkg.Engine(nx, ny, rank=1, nranks=2, halo=8)]
+    try:
+        with pytest.raises(pkg.WTError):
+            pkg.Engine.link_local(es)
+    finally:
+        for e in es:
+            e.close()
+
+
+def test_strongly_uneven_split_plans_one_schedule(pkg):
+    """eligibility and steps per pass come from the SPLIT (widest slab below 4 GiB, narrowest slab's columns per unit), never from
+    a rank's own width — a 3000-column slab next to a 100-column one plan alike and run bit-identically to the whole lattice."""
+    nx, ny, halo = 3300, 1024, 16
+    edges = [0, 100, 3100, 3300]
+    mask = pkg.geometry.build_geometry(nx, ny, 5.0, None, "naca2412").mask
+    f0, m0, _, _ = _single(pkg, mask, [40], 0.58, 0.06, "float32")
+    es = [pkg.Engine(nx, ny, rank=r, nranks=3, halo=halo, edges=edges) for r in range(3)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        assert len({(e.get_option("fuse_active"), e.get_option("fuse_depth")) for e in es}) == 1
+        for n in (1, 5, 17, 40, 100):
+            assert len({tuple(e.plan_steps(n, 0.58)) for e in es}) == 1
+        pkg.Engine.step_group(es, 40, 0.58, 0.06)
+        f1 = np.concatenate([e.read_f() for e in es], axis=2)
+        assert all(e.get_option("chain_downgrades") == 0 for e in es)
+    finally:
+        for e in es:
+            e.close()
+    assert bits_equal(f0, f1)
+
+
+def test_exchange_timing_of_a_local_group(pkg):
+    """option exchange_timing: events around every ghost exchange and the interior kernel beside it (bench.py --gpus N prints them per rank)."""
+    nx, ny, nranks, halo = 2048, 1024, 2, 17
+    mask = pkg.geometry.build_geometry(nx, ny, 7.0, None, "naca2412").mask
+    es = [pkg.Engine(nx, ny, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_mask(mask); e.init_equilibrium(0.06)
+            e.set_option("exchange_timing", 1)
+        pkg.Engine.step_group(es, 17 * 40, 0.58, 0.06)          # 40 refresh cycles: the ring of 32 is folded once on the way
+        for e in es:
+            n = e.get_option("exchanges")
+            assert 38 <= n <= 41, n
+            x, i, w = e.get_option("exchange_ms"), e.get_option("interior_ms"), e.get_option("exchange_exposed_ms")
+            assert x > 0 and i > 0 and w >= 0 and x / n < 5.0 and i / n < 5.0, (x, i, w)
+            e.set_option("exchange_timing", 0)
+            assert e.get_option("exchanges") == 0
+    finally:
+        for e in es:
+            e.close()
+
+
+def test_pass_depth_reports_the_pass_actually_taken(pkg):
+    """"fuse_depth" is what the tables are built for, "pass_depth" what a full pass takes for the tau in use — 3 on a four-step
+    fp32 plan while the division by tau has to be the IEEE one."""
+    nx, ny = 4096, 1024
+    mask = pkg.geometry.build_geometry(nx, ny, 5.0, None, "naca2412").mask
+    with pkg.Engine(nx, ny) as e:
+        e.set_option("fuse_depth", 4); e.set_option("fuse_steps", 2)
+        e.set_mask(mask); e.init_equilibrium(0.06)
+        e.step(8, 0.58, 0.06)
+        assert (e.get_option("fuse_depth"), e.get_option("pass_depth"), e.get_option("passes")) == (4, 4, 2)
+        e.set_option("fast_div", 0)
+        e.init_equilibrium(0.06)
+        assert e.get_option("passes") == 0                    # counted since the last init / write_f, like single_steps
+        e.step(9, 0.58, 0.06)
+        assert (e.get_option("fuse_depth"), e.get_option("pass_depth"), e.get_option("passes")) == (4, 3, 3)
