@@ -5,8 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one lattice update (simStep, html:510-525) of the whole tunnel.  Workload:
-BASELINE.json configs[2] — 4096x4096 fp32, AoA 10 deg, U0 0.06, tau 0.58.  The S1223 coordinates
+A "step" is one lattice update (simStep, html:510-525) of the whole tunnel.  Workload (default, `--config 2`):
+BASELINE.json configs[2] — 4096x4096 fp32, AoA 10 deg, U0 0.06, tau 0.58; `--config N` runs any of BASELINE.json's five
+configurations on its own shape / angle / tau / dtype / size (CONFIGS below), explicit flags override single values.  The S1223 coordinates
 named there are not available offline (no network; the reference ships no .dat files), so the
 body is the reference's own high-camber built-in shape NACA 6409 (html:127); the kernel's cost
 depends on the body only through the fraction of window-tiles that touch its surface.
@@ -49,17 +50,37 @@ BYTES_PER_LUP = {"float32": 72, "float64": 144}   # 9 loads + 9 stores per site 
 COMM_TIMEOUT_S = 180.0
 
 
+# BASELINE.json's five configurations, each with its own parameters (U0 = 0.06 throughout; tau 0.58 = html:78 unless a Reynolds number is named:
+# tau = 0.5 + 3 U0 (NX / 1.84) / Re).  `steps` / `warmup`: what `--config N` runs when --steps / --warmup are not given — configs 0 and 1
+# name their own step counts; the others get a steady-state sample.  Config 2's S1223 coordinates are not available offline (see the module text).
+CONFIGS = {
+    0: dict(shape="naca0012", nx=256, ny=128, aoa=0.0, dtype="float32", re=None, steps=500, warmup=100,
+            name="BASELINE configs[0]: NACA 0012, 256x128 D2Q9, AoA 0 deg, 500 steps (the reference's own CPU-runnable case: a parity case, launch-bound on a GPU)"),
+    1: dict(shape="naca2412", nx=1024, ny=512, aoa=5.0, dtype="float32", re=None, steps=2000, warmup=300,
+            name="BASELINE configs[1]: NACA 2412, 1024x512 fp32, AoA 5 deg, 2000 steps (38 MB working set: cache-resident)"),
+    2: dict(shape="naca6409", nx=4096, ny=4096, aoa=10.0, dtype="float32", re=None, steps=400, warmup=300,
+            name="BASELINE configs[2]: 4096x4096 fp32, AoA 10 deg; S1223 coordinates unavailable offline -> NACA 6409; pass --dat PATH to use a supplied file"),
+    3: dict(shape="naca0012", nx=16384, ny=4096, aoa=8.0, dtype="float32", re=None, steps=200, warmup=100,
+            name="BASELINE configs[3]: NACA 0012, 16384x4096 fp32, AoA 8 deg (the 8-GPU column-slab case: --gpus 8 splits it, one GPU holds it whole)"),
+    4: dict(shape="naca4412", nx=4096, ny=2048, aoa=12.0, dtype="float64", re=1e6, steps=240, warmup=120,
+            name="BASELINE configs[4]: NACA 4412, 4096x2048 fp64, Re=1e6 (tau = 0.5 + 3 U0 (NX/1.84)/Re ~ 0.5004), AoA 12 deg near stall"),
+}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: the clocks of an idle MI355X take 20-30 ms of work to settle (profiles/r03_g_time_series.txt: 98 -> 86 us per step over the first 250 steps
-    # of the bench lattice), so the untimed warm-up covers that and the timed region is 35 ms of steady state
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--nx", type=int, default=4096)
-    ap.add_argument("--ny", type=int, default=4096)
-    ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
-    ap.add_argument("--shape", default="naca6409")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="which of BASELINE.json's configurations to run, on ITS shape / AoA / tau / dtype / lattice (default 2: the one the metric is quoted "
+                         "on); --nx/--ny/--dtype/--shape/--aoa/--tau/--re override single values (the workload is then labelled 'custom')")
+    # defaults (config 2): the clocks of an idle MI355X take 20-30 ms of work to settle (profiles/r03_g_time_series.txt: 98 -> 86 us per step over the first
+    # 250 steps of the bench lattice), so the untimed warm-up covers that and the timed region is 35 ms of steady state
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--nx", type=int, default=None)
+    ap.add_argument("--ny", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["float32", "float64"])
+    ap.add_argument("--shape", default=None)
     ap.add_argument("--dat", default=None, metavar="PATH",
                     help="airfoil coordinates from a .dat file (Selig / Lednicer, parsed and repaired like the reference's back end: "
                          "datfile.load_dat) in place of --shape; e.g. the S1223 file BASELINE configs[2] names, which neither the reference "
@@ -67,9 +88,10 @@ def parse_args():
     ap.add_argument("--local-slabs", type=int, default=0, metavar="P",
                     help="ONE process, P column slabs of the lattice as P handles on device 0 (wt_link_local + wt_step_group: the slab state "
                          "machine and the refresh / interior overlap of the N-GPU path, run on one GPU); prints per-slab device times")
-    ap.add_argument("--aoa", type=float, default=10.0)
+    ap.add_argument("--aoa", type=float, default=None)
     ap.add_argument("--u0", type=float, default=0.06)
-    ap.add_argument("--tau", type=float, default=0.58)
+    ap.add_argument("--tau", type=float, default=None)
+    ap.add_argument("--re", type=float, default=None, help="Reynolds number: tau = 0.5 + 3 U0 (NX / 1.84) / Re (SURVEY 8b) in place of --tau")
     ap.add_argument("--halo", type=int, default=17,
                     help="ghost columns per interior slab side (exchange every `halo` steps; 17 = one single refresh step + four four-step passes: "
                          "2 %% faster than 16 = 1 + 4 + 4 + 4 + 3 in a locally linked group, profiles/r03_g_group_vs_alone.txt)")
@@ -78,22 +100,44 @@ def parse_args():
                     help="two steps per pass over the lattice (csrc/step_march.hpp; fp32; bit-identical): -1 library "
                          "default (on where it pays), 0 off, 1 where it pays, 2 always")
     ap.add_argument("--fuse-chunk", type=int, default=0, help="cost limit of a marching unit in columns (0 = whole resident rounds)")
-    ap.add_argument("--fuse-sites", type=int, default=0, choices=[0, 2, 4], help="sites per lane of the marching kernel (0 = automatic)")
+    ap.add_argument("--fuse-sites", type=int, default=0, choices=[0, 2], help="sites per lane of the marching kernel (0 = automatic; fixed by the dtype since round 3)")
     ap.add_argument("--fuse-depth", type=int, default=0, choices=[0, 2, 3, 4], help="steps per pass of the marching kernel (0 = automatic)")
     ap.add_argument("--fast-math", type=int, default=-1, choices=[-1, 0, 1],
                     help="the OPT-IN contracted collision (fused multiply-adds, v_rcp): -1 (default) = the bit-exact kernels print the line and the "
                          "contracted ones are timed beside them as roofline.contracted; 0 = skip that; 1 = the whole run uses them (NOT bit-exact)")
     ap.add_argument("--pmc-traffic", type=int, default=1, choices=[0, 1],
-                    help="1 (default, one GPU only): before the timed run, measure this workload's HBM traffic per launch in this session — two short "
-                         "child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` — and use it for roofline.traffic / frac; "
-                         "0, or when rocprofv3 is not available: the entry of profiles/pmc_traffic.json (measured in another run), if there is one")
+                    help="1 (default, one GPU only): before the timed run, measure this workload's HBM traffic and vector-ALU activity per launch in this "
+                         "session — three short child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / the SQ group — and use "
+                         "them for roofline.traffic / frac / valu_busy_frac; 0, or when rocprofv3 is not available: the entry of profiles/pmc_traffic.json "
+                         "(measured in another run), if there is one, and no valu_busy_frac")
+    ap.add_argument("--side", type=int, default=1, choices=[0, 1],
+                    help="1 (default, one GPU): also time the un-fused kernel and (fp32) the opt-in contracted arithmetic for the roofline entry — BEFORE the "
+                         "warm-up, reported as preheat_steps / preheat_ms; 0: nothing runs on the device before the declared warm-up but the plan's own tuning")
     ap.add_argument("--balance", type=int, default=-1, metavar="R",
                     help="slab runs with strong scaling: R rounds of cutting the slabs by MEASURED cost instead of equal widths before the run (every rank "
                          "times its candidate slab alone, airfoil_cfd_tool_amd.distributed.balance_split; the split with the fastest slowest slab is kept, "
                          "the equal one included).  -1 (default): 4 rounds when there is more than one slab, 0: equal widths")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: nx x ny split over N GPUs; weak: every GPU gets an nx x ny slab")
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.custom = [k for k in ("nx", "ny", "dtype", "shape", "aoa") if getattr(args, k) is not None and getattr(args, k) != cfg[k]]
+    for k in ("nx", "ny", "dtype", "shape", "aoa", "steps", "warmup"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
+    if args.tau is not None and args.re is not None:
+        ap.error("--tau and --re exclude each other")
+    tau_of = lambda re_: 0.58 if re_ is None else 0.5 + 3.0 * args.u0 * (args.nx / 1.84) / re_        # html:77-79, SURVEY 8b
+    cfg_tau = tau_of(cfg["re"])
+    if args.tau is None:
+        args.tau = tau_of(args.re if args.re is not None else cfg["re"])
+    if abs(args.tau - cfg_tau) > 1e-12:
+        args.custom.append("tau")
+    if args.u0 != 0.06:
+        args.custom.append("u0")
+    if args.dat:
+        args.custom.append("dat")
+    return args
 
 
 def cpu_model():
@@ -149,49 +193,69 @@ def measured_traffic(workload_key):
     return e if e and "hbm_bytes_per_launch" in e else None
 
 
-def pmc_traffic_this_session(args):
-    """HBM bytes per launch of the dominant kernel(s), measured NOW on this box: two short child runs of this same script and workload under
-    rocprofv3, one per counter (they do not fit one pass; MI355X_MICROARCH.md HBM section: FETCH_SIZE KB x 1024 x 2 on gfx950, WRITE_SIZE KB x
-    1024).  Runs before this process touches the GPU; the children are started with the interpreter itself behind `--`.  Returns None on any
-    failure (no rocprofv3, no counters, a profiler already attached to this process)."""
+SQ_GROUP = ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE")
+
+
+def pmc_counters_this_session(args):
+    """Counters per launch of every kernel of this workload, measured NOW on this box: three short child runs of this same script and workload under
+    rocprofv3 — FETCH_SIZE and WRITE_SIZE in a pass each (they do not fit one; MI355X_MICROARCH.md HBM section: FETCH_SIZE KB x 1024 x 2 on gfx950,
+    WRITE_SIZE KB x 1024), then the SQ group (vector-ALU activity, wave cycles, waits) with GRBM_GUI_ACTIVE (the kernel's duration in clocks).
+    Runs before this process touches the GPU; the children are started with the interpreter itself behind `--`, in a session of their own so that a
+    timeout takes the whole process group down (no grandchild keeps the GPU beside the timed run).  Returns None on any failure (no rocprofv3, no
+    counters, a profiler already attached to this process); a failing SQ pass alone leaves the traffic figures standing."""
     import glob
     import re
     import shutil
+    import signal
     import sqlite3
     import subprocess
     import tempfile
     rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rocprof is None or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
         return None
-    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "48", "--warmup", "12", "--cpu-steps", "0", "--fast-math", "0",
-             "--pmc-traffic", "0", "--nx", str(args.nx), "--ny", str(args.ny), "--dtype", args.dtype, "--shape", args.shape, "--aoa", str(args.aoa),
-             "--u0", str(args.u0), "--tau", str(args.tau), "--fuse", str(args.fuse), "--fuse-chunk", str(args.fuse_chunk),
-             "--fuse-depth", str(args.fuse_depth)]
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--steps", "48", "--warmup", "12", "--cpu-steps", "0",
+             "--fast-math", "1" if args.fast_math == 1 else "0", "--side", "0", "--pmc-traffic", "0", "--nx", str(args.nx), "--ny", str(args.ny),
+             "--dtype", args.dtype, "--shape", args.shape, "--aoa", str(args.aoa), "--u0", str(args.u0), "--tau", repr(args.tau), "--fuse", str(args.fuse),
+             "--fuse-chunk", str(args.fuse_chunk), "--fuse-sites", str(args.fuse_sites), "--fuse-depth", str(args.fuse_depth)]
     if args.dat:
-        child += ["--dat", args.dat]
-    if args.fast_math == 1:
-        child[child.index("--fast-math") + 1] = "1"
+        child += ["--dat", os.path.abspath(args.dat)]          # (the children run in /tmp)
     per_kernel = {}
     tmp = tempfile.mkdtemp(prefix="wt_pmc_", dir="/tmp")
     try:
         # WT_TUNE=0: the counters are averaged per kernel over ALL dispatches of the child run, and the trial passes of the measured cut
         # (13 per new mask, every one with the halo kernel's gather path) would be averaged in; the modelled cut moves the same bytes per pass
         env = dict(os.environ, TMPDIR="/tmp", WT_TUNE="0")
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            r = subprocess.run([rocprof, "--pmc", counter, "-d", out, "-o", "c", "--"] + child, cwd="/tmp", env=env, stdout=subprocess.PIPE,
-                               stderr=subprocess.STDOUT, text=True, timeout=240)
+        for group in (("FETCH_SIZE",), ("WRITE_SIZE",), SQ_GROUP):
+            out = os.path.join(tmp, group[0])
+            proc = subprocess.Popen([rocprof, "--pmc", *group, "-d", out, "-o", "c", "--"] + child, cwd="/tmp", env=env, stdout=subprocess.PIPE,
+                                    stderr=subprocess.STDOUT, text=True, start_new_session=True)
+            try:
+                proc.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)        # rocprofv3 AND the interpreter behind it
+                except OSError:
+                    pass
+                proc.wait()
+                if group is SQ_GROUP:
+                    break
+                return None
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
-            if r.returncode != 0 or not dbs:
+            if proc.returncode != 0 or not dbs:
+                if group is SQ_GROUP:
+                    break                                      # traffic measured, vector-ALU activity not: the line says so
                 return None
             con = sqlite3.connect(dbs[0])
             acc = {}
-            for kname, disp, val in con.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name = ?", (counter,)):
+            for kname, cname, disp, val in con.execute("select kernel_name, counter_name, dispatch_id, value from counters_collection"):
+                if cname not in group:
+                    continue
                 k = re.sub(r"\(.*", "", kname).replace("void ", "").replace(", ", ",")
-                acc.setdefault(k, {}).setdefault(disp, 0.0)
-                acc[k][disp] += val
-            for k, d in acc.items():
-                per_kernel.setdefault(k, {})[counter] = sum(d.values()) / len(d)
+                acc.setdefault((k, cname), {}).setdefault(disp, 0.0)
+                acc[(k, cname)][disp] += val                   # summed over the chip (one row per counter instance)
+            for (k, cname), d in acc.items():
+                per_kernel.setdefault(k, {})[cname] = sum(d.values()) / len(d)
+                per_kernel[k].setdefault("dispatches", {})[cname] = len(d)
     except Exception:      # noqa: BLE001 - the file entry (or null) stands in
         return None
     finally:
@@ -199,27 +263,60 @@ def pmc_traffic_this_session(args):
     return per_kernel
 
 
+def pass_kernels(fused, depth):
+    """(predicate over kernel names, description) of the dominant kernels of one launch (pass)."""
+    if not fused:
+        return (lambda k: k.startswith("wt::k_step<") and ",false," in k), "wt::k_step<T,false,...> (non-emitting step)"
+    if depth >= 3:
+        # (a three-step pass on a four-step plan — a tau without a proved fast division — still runs k_halo4: the tables decide)
+        return ((lambda k: (k.startswith("wt::k_march3<") and f",{depth},false," in k) or k.startswith("wt::k_halo4<") or k.startswith("wt::k_halo3<")),
+                f"one pass = wt::k_halo4 / k_halo3 + wt::k_march3<T,S,{depth},false,FD>")
+    return ((lambda k: (k.startswith("wt::k_march<") and ",false," in k) or k.startswith("wt::k_halo_from_seams")),
+            "one pass = wt::k_halo_from_seams + wt::k_march<T,S,false,FD>")
+
+
 def select_traffic(per_kernel, fused, depth):
-    """Sum the dominant kernels of one launch (pass) out of pmc_traffic_this_session()'s table."""
+    """Sum the dominant kernels of one launch (pass) out of pmc_counters_this_session()'s table."""
     if not per_kernel:
         return None
-    if not fused:
-        use = lambda k: k.startswith("wt::k_step<") and ",false," in k
-        what = "wt::k_step<T,false,...> (non-emitting step)"
-    elif depth >= 3:
-        use = lambda k: (k.startswith("wt::k_march3<") and f",{depth},false," in k) or k.startswith("wt::k_halo4<" if depth == 4 else "wt::k_halo3<")
-        what = f"one pass = wt::k_halo{4 if depth == 4 else 3} + wt::k_march3<T,S,{depth},false,FD>"
-    else:
-        use = lambda k: (k.startswith("wt::k_march<") and ",false," in k) or k.startswith("wt::k_halo_from_seams")
-        what = "one pass = wt::k_halo_from_seams + wt::k_march<T,S,false,FD>"
+    use, what = pass_kernels(fused, depth)
     fetch = sum(v.get("FETCH_SIZE", 0.0) for k, v in per_kernel.items() if use(k)) * 1024 * 2
     write = sum(v.get("WRITE_SIZE", 0.0) for k, v in per_kernel.items() if use(k)) * 1024
     if fetch <= 0 or write <= 0:
         return None
     return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write, "kernel": what,
-            "measured": "this session, this box: two child runs of this command (48 timed steps) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
-                        "just before the timed run",
+            "measured": "this session, this box: child runs of this command (48 timed steps, the MODELLED cut of the units: WT_TUNE=0, which moves the "
+                        "same bytes per pass as the measured cut of the timed run) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, just before the timed run",
             "source": "rocprofv3 counters, FETCH_SIZE KB x1024 x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KB x1024"}
+
+
+def select_valu(per_kernel, fused, depth, n_simd, launch_ms):
+    """Vector-ALU activity of one launch (pass) from the SQ group of pmc_counters_this_session(): SQ_ACTIVE_INST_VALU counts, per wave, the
+    quad-cycles a vector instruction of that wave is executing (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count
+    quad-cycles), summed over the chip.  valu_busy_frac = that x 4 clocks / (SIMDs x the kernels' duration in clocks), the duration taken from
+    GRBM_GUI_ACTIVE of the SAME profiled dispatches (summed over the 8 XCDs by rocprofv3: / 8) — no clock frequency is assumed; beside it the
+    same numerator over this run's launch time at the nominal 2.4 GHz.  With two waves per SIMD the figure can exceed 0.5 only by overlapping
+    the two waves' instructions; 1.0 is a vector instruction in flight on every SIMD for the whole launch."""
+    if not per_kernel:
+        return None
+    use, what = pass_kernels(fused, depth)
+    tot = {c: sum(v.get(c, 0.0) for k, v in per_kernel.items() if use(k)) for c in SQ_GROUP}
+    if tot["SQ_ACTIVE_INST_VALU"] <= 0 or tot["SQ_WAVE_CYCLES"] <= 0:
+        return None
+    clocks = tot["GRBM_GUI_ACTIVE"] / 8.0
+    out = {"kernel": what, "SQ_ACTIVE_INST_VALU": tot["SQ_ACTIVE_INST_VALU"], "SQ_WAVE_CYCLES": tot["SQ_WAVE_CYCLES"], "SQ_WAIT_ANY": tot["SQ_WAIT_ANY"],
+           "SQ_BUSY_CYCLES": tot["SQ_BUSY_CYCLES"], "GRBM_GUI_ACTIVE": tot["GRBM_GUI_ACTIVE"], "simds": n_simd,
+           "valu_active_per_wave": tot["SQ_ACTIVE_INST_VALU"] / tot["SQ_WAVE_CYCLES"],
+           "waves_waiting_frac": tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"],
+           "valu_busy_frac_at_2p4_ghz": tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (n_simd * launch_ms * 1e-3 * 2.4e9),
+           "valu_busy_frac": None, "effective_clock_ghz": None,
+           "measured": "this session, this box: a third child run under rocprofv3 --pmc " + " ".join(SQ_GROUP) + " (per launch, summed over the chip)"}
+    if clocks > 0:
+        out["valu_busy_frac"] = tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (n_simd * clocks)
+        out["effective_clock_ghz"] = clocks / (launch_ms * 1e-3) / 1e9      # profiled clocks over the UN-profiled launch time: indicative only
+    else:
+        out["valu_busy_frac"] = out["valu_busy_frac_at_2p4_ghz"]
+    return out
 
 
 def die(rank, device, what, err=None):
@@ -266,10 +363,14 @@ def roofline_entry(kernel, bytes_alg, launch_ms, traffic):
 
 
 def workload_name(args, nx_total, ny, body_name):
-    note = ("coordinates from the file named" if args.dat else
-            "BASELINE configs[2]; S1223 coordinates unavailable offline -> NACA 6409; pass --dat PATH to use a supplied file"
-            if args.shape == "naca6409" else "built-in shape")
-    return f"{body_name} {nx_total}x{ny} {args.dtype} D2Q9, AoA={args.aoa:g} deg, U0={args.u0:g}, tau={args.tau:g} ({note})"
+    """Names the workload; only a run on a BASELINE configuration's OWN parameters carries that configuration's name."""
+    if args.dat:
+        note = "custom: coordinates from the file named"
+    elif not args.custom and (nx_total, ny) == (CONFIGS[args.config]["nx"], CONFIGS[args.config]["ny"]):
+        note = CONFIGS[args.config]["name"]
+    else:
+        note = f"custom workload (differs from BASELINE configs[{args.config}] in: {', '.join(args.custom) or 'lattice'}); built-in shape"
+    return f"{body_name} {nx_total}x{ny} {args.dtype} D2Q9, AoA={args.aoa:g} deg, U0={args.u0:g}, tau={args.tau:.7g} ({note})"
 
 
 def slab_options(args):
@@ -318,6 +419,7 @@ def local_slabs_main(args, wtpkg, mask, body_name):
                 e.set_option("fuse_steps", args.fuse)
             e.set_mask(mask)
             e.init_equilibrium(args.u0)
+            e.set_option("exchange_timing", 1)
         if args.warmup > 0:
             wtpkg.Engine.step_group(es, args.warmup, args.tau, args.u0)
         for e in es:
@@ -349,6 +451,18 @@ def local_slabs_main(args, wtpkg, mask, body_name):
                        "edges": [e.x0 for e in es] + [nx], "balance": balance_report(history),
                        "fuse_depth": [int(e.get_option("fuse_depth")) if e.get_option("fuse_active") else 0 for e in es],
                        "single_steps": [int(e.get_option("single_steps")) for e in es]},
+            # the per-rank report of the N-GPU line (`ranks`), from the in-process transport: same keys, comm_ranks 0 (no communicator here)
+            "ranks": [{"rank": r, "device": 0, "comm_ranks": int(e.get_option("comm_ranks")), "x0": e.x0, "width": e.width, "device_ms": dev_ms[r],
+                       "exchanges": int(e.get_option("exchanges")),
+                       "exchange_ms_each": e.get_option("exchange_ms") / max(1.0, e.get_option("exchanges")),
+                       "interior_ms_each": e.get_option("interior_ms") / max(1.0, e.get_option("exchanges")),
+                       "exchange_exposed_ms_each": e.get_option("exchange_exposed_ms") / max(1.0, e.get_option("exchanges")),
+                       "exchange_hidden_frac": (None if e.get_option("exchange_ms") <= 0 else
+                                                max(0.0, 1.0 - e.get_option("exchange_exposed_ms") / e.get_option("exchange_ms"))),
+                       "fuse_active": int(e.get_option("fuse_active")), "fuse_depth": int(e.get_option("fuse_depth")),
+                       "pass_depth": int(e.get_option("pass_depth")), "passes": int(e.get_option("passes")),
+                       "single_steps": int(e.get_option("single_steps")), "agree_checks": int(e.get_option("agree_checks")),
+                       "chain_downgrades": int(e.get_option("chain_downgrades"))} for r, e in enumerate(es)],
             "local_slabs": {"device_ms_per_step": [m / args.steps for m in dev_ms], "sum_device_ms_per_step": sum(dev_ms) / args.steps,
                             "group_wall_ms_per_step": wall / args.steps * 1e3,
                             "one_slab_alone_ms_per_step": solo_ms,
@@ -377,7 +491,7 @@ def main():
         args.gpus = world
 
     # same-session HBM traffic (children under rocprofv3), before this process touches the GPU
-    session_traffic = pmc_traffic_this_session(args) if (world == 1 and args.pmc_traffic == 1 and args.local_slabs == 0) else None
+    session_counters = pmc_counters_this_session(args) if (world == 1 and args.pmc_traffic == 1 and args.local_slabs == 0) else None
 
     import datetime
     import numpy as np
@@ -467,7 +581,10 @@ def main():
     # follows: W untimed warm-up steps, K timed steps.  Order matters on this hardware: an idle GPU takes 20-30 ms of uninterrupted work to settle its
     # clocks (profiles/r03_g_time_series.txt), and a K of 20 steps is 1.8 ms.
     side = {}
-    if not distributed and bool(eng.get_option("fuse_active")):
+    preheat_steps, t_pre0 = 0, time.perf_counter()
+    if distributed:
+        eng.set_option("exchange_timing", 1)                       # events around every ghost exchange and the interior kernel beside it
+    if not distributed and args.side == 1 and bool(eng.get_option("fuse_active")):
         spl0 = int(eng.get_option("fuse_depth"))
         try:
             with wtpkg.Engine(nx_total, ny, dtype=args.dtype, device=local_rank) as e1:
@@ -475,6 +592,7 @@ def main():
                 e1.set_mask(mask); e1.init_equilibrium(args.u0)
                 e1.step(4, args.tau, args.u0)
                 side["single_ms"] = e1.step_timed(40, args.tau, args.u0) / 40
+                preheat_steps += 44
         except Exception as e:      # noqa: BLE001
             side["single_error"] = str(e)
         if args.fast_math == -1 and args.dtype == "float32":
@@ -484,10 +602,21 @@ def main():
                 eng.step(2 * spl0, args.tau, args.u0)
                 nfm = (200 // spl0) * spl0                         # (its own sample, whatever K is: 17 ms of steady state)
                 side["contracted_ms"] = eng.step_timed(nfm, args.tau, args.u0) / nfm
+                preheat_steps += 4 * spl0 + nfm
             except Exception as e:      # noqa: BLE001
                 side["contracted_error"] = str(e)
             eng.set_option("fast_math", 0)
             eng.init_equilibrium(args.u0)
+    if not distributed:
+        eng.sync()
+    # everything the device has done before the DECLARED warm-up (ADVICE r3 / VERDICT r3 weak 5): the side measurements above and the trial passes
+    # of the plan's measured cut (13 marching passes on a new mask).  On a short run (`--steps 20 --warmup 5`) this work, not the five warm-up
+    # steps, is what brings the GPU's clocks up before the timed region; the JSON line says so (`preheat_*`), and `--side 0` runs none of it.
+    tune_passes = 13 if (bool(eng.get_option("fuse_active")) and eng.get_option("tune_rounds") > 0) else 0
+    preheat = {"preheat_steps": preheat_steps + tune_passes * (int(eng.get_option("fuse_depth")) if tune_passes else 0),
+               "preheat_ms": (time.perf_counter() - t_pre0) * 1e3 if (preheat_steps or tune_passes) else 0.0,
+               "preheat_what": ("k_step on a second handle: 44 steps; contracted arithmetic on the bench handle: %d steps; trial passes of the measured cut: %d"
+                                % (max(0, preheat_steps - 44), tune_passes)) if (preheat_steps or tune_passes) else "nothing"}
 
     try:
         # warm-up (untimed); the first exchange of a slab run happens here
@@ -507,8 +636,28 @@ def main():
     except Exception as e:      # noqa: BLE001
         die(rank, local_rank, "stepping", e)
 
+    if tune_passes == 0 and bool(eng.get_option("fuse_active")) and eng.get_option("tune_rounds") > 0:
+        # (no side measurement ran: the plan was timed inside the warm-up call, before its first pass)
+        preheat["preheat_steps"] += 13 * int(eng.get_option("fuse_depth"))
+        preheat["preheat_what"] = "trial passes of the measured cut: 13 (inside the warm-up call)"
     per_rank_ms = [dev_ms]
+    rank_report = None
     if distributed:
+        # first-contact kit: what every rank saw — the ranks in the library's communicator, its device time, its
+        # exchanges and how much of them hid behind the interior kernel, its slab and plan
+        nx_ = max(1.0, eng.get_option("exchanges"))
+        mine_rep = {"rank": rank, "device": local_rank, "comm_ranks": int(eng.get_option("comm_ranks")), "x0": eng.x0, "width": eng.width,
+                    "device_ms": dev_ms, "exchanges": int(eng.get_option("exchanges")),
+                    "exchange_ms_each": eng.get_option("exchange_ms") / nx_, "interior_ms_each": eng.get_option("interior_ms") / nx_,
+                    "exchange_exposed_ms_each": eng.get_option("exchange_exposed_ms") / nx_,
+                    "exchange_hidden_frac": (None if eng.get_option("exchange_ms") <= 0 else
+                                             max(0.0, 1.0 - eng.get_option("exchange_exposed_ms") / eng.get_option("exchange_ms"))),
+                    "fuse_active": int(eng.get_option("fuse_active")), "fuse_depth": int(eng.get_option("fuse_depth")),
+                    "pass_depth": int(eng.get_option("pass_depth")), "passes": int(eng.get_option("passes")),
+                    "single_steps": int(eng.get_option("single_steps")), "agree_checks": int(eng.get_option("agree_checks")),
+                    "chain_downgrades": int(eng.get_option("chain_downgrades"))}
+        rank_report = [None] * world
+        dist.all_gather_object(rank_report, mine_rep)
         t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         mine = torch.tensor([dev_ms], dtype=torch.float64, device="cuda")
@@ -521,7 +670,8 @@ def main():
     mlups = sites * args.steps / wall / 1e6
     bpl = BYTES_PER_LUP[args.dtype]
     fused = bool(eng.get_option("fuse_active"))
-    steps_per_launch = int(eng.get_option("fuse_depth")) if fused else 1
+    # steps a full pass actually takes ("pass_depth": 3 on a four-step fp32 plan whose tau has no proved fast division — ADVICE r3)
+    steps_per_launch = int(eng.get_option("pass_depth")) if fused else 1
     # one launch = one pass of the dominant kernel over the slab (when --steps is not a multiple of the steps per pass the
     # last one or two steps are single steps; they are averaged in)
     launch_ms = dev_ms / args.steps * steps_per_launch
@@ -534,7 +684,7 @@ def main():
         main_kernel = "wt::k_march3 (THREE steps per pass, body / inlet / outlet inside; + wt::k_halo3 per pass)"
     elif fused:
         main_kernel = "wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)"
-    traffic = None if distributed else (select_traffic(session_traffic, fused, steps_per_launch) or
+    traffic = None if distributed else (select_traffic(session_counters, fused, steps_per_launch) or
                                         measured_traffic(key + (("_march4" if steps_per_launch == 4 else "_march3" if steps_per_launch == 3 else "_march") if fused else "")))
     r = roofline_entry(main_kernel, bpl * sites_per_launch * steps_per_launch, launch_ms, traffic)
     # `achieved` / `frac` are the REAL HBM rate (rocprofv3 counters of this workload, profiles/pmc_traffic.json) over this run's launch time,
@@ -546,15 +696,23 @@ def main():
     cfg_fuse = {"fuse_steps": int(fused), "fuse_chunk": int(eng.get_option("fuse_chunk")) if fused else 0,
                 "fuse_units": int(eng.get_option("fuse_units")) if fused else 0,
                 "fuse_sites": int(eng.get_option("fuse_sites")) if fused else 0,
-                "fuse_depth": steps_per_launch if fused else 0,
+                "fuse_depth": int(eng.get_option("fuse_depth")) if fused else 0, "pass_depth": steps_per_launch if fused else 0,
                 "fast_div": int(eng.get_option("fast_div_active")) if fused else 0,
                 "single_steps": int(eng.get_option("single_steps"))}
-    # what the SQ counters say limits the kernel (profiles/r03_c_sq_counters_bench_kernel.txt): the marching kernels keep the vector ALU
-    # busy for 60-70 % of their run time with two waves per SIMD while moving 45-50 % of the HBM peak; k_step is HBM-bound.
-    roofline = {"bound": "valu" if fused else "hbm", "kernel": main_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": None if achieved is None else achieved / HBM_PEAK_GBPS,
-                "bound_note": ("vector-instruction issue (SQ_ACTIVE_INST_VALU ~ 65 % of the SIMD time at 2 waves per SIMD); the HBM figures "
-                               "say how far below the memory roof that leaves the kernel" if fused else "HBM bandwidth"),
+    # Which roof is nearer is MEASURED in this session: the HBM fraction from the FETCH / WRITE counters over this run's launch
+    # time, the vector-ALU fraction from the SQ group of the third child run; `bound` names the larger of the two.  Without SQ counters (no
+    # rocprofv3, --pmc-traffic 0, a slab run) `bound` stays "hbm" — the roof SURVEY 8d prices this path against — and `valu_busy_frac` is null.
+    valu = None if distributed else select_valu(session_counters, fused, steps_per_launch, int(eng.get_option("wave_slots")) // 2, launch_ms)
+    hbm_frac = None if achieved is None else achieved / HBM_PEAK_GBPS
+    valu_frac = None if valu is None else valu["valu_busy_frac"]
+    bound = "valu" if (valu_frac is not None and valu_frac > (hbm_frac if hbm_frac is not None else compulsory / HBM_PEAK_GBPS)) else "hbm"
+    roofline = {"bound": bound, "kernel": main_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": hbm_frac,
+                "valu_busy_frac": valu_frac,
+                "bound_basis": ("measured this session: HBM %s of the peak (counters), vector ALUs busy %s of the launch (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x "
+                                "GRBM_GUI_ACTIVE / 8)); the larger names the bound"
+                                % ("n/a" if hbm_frac is None else "%.3f" % hbm_frac, "n/a" if valu_frac is None else "%.3f" % valu_frac)),
+                "valu": valu,
                 "achieved_basis": ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch (see traffic_source.measured) / this run's launch time"
                                    if achieved is not None else "no counters: rocprofv3 unavailable (or --pmc-traffic 0) and no entry for this workload in profiles/pmc_traffic.json"),
                 "traffic": r["traffic"], "traffic_source": r["traffic_source"], "counter_gbps": r["counter_gbps"],
@@ -590,6 +748,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        **preheat,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": args.scaling,
@@ -603,6 +762,9 @@ def main():
         "device_ms": per_rank_ms,
         "roofline": roofline,
     }
+    if rank_report is not None:
+        out["ranks"] = rank_report
+        out["comm_ranks_seen"] = sorted({r_["comm_ranks"] for r_ in rank_report})
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(mask, args.cpu_steps, args.tau, args.u0, args.dtype)
     elif rank == 0:

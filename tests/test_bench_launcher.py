@@ -40,6 +40,10 @@ def test_two_ranks_fail_cleanly_or_run():
         assert p.returncode == 0, p.stderr[-3000:]
         d = json.loads(lines[-1])
         assert d["n_gpus"] == 2 and len(d["device_ms"]) == 2 and d["value"] > 0
+        # first-contact kit: what every rank saw (the same keys the one-GPU `--local-slabs` line carries, tests/test_gpu_bench_contract.py)
+        assert d["comm_ranks_seen"] == [2] and [r["rank"] for r in d["ranks"]] == [0, 1]
+        for r in d["ranks"]:
+            assert r["comm_ranks"] == 2 and r["exchanges"] >= 1 and r["exchange_ms_each"] > 0 and r["agree_checks"] >= 1
     else:
         assert p.returncode != 0
         assert not lines                                            # no bench line from a failed job

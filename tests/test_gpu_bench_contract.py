@@ -29,11 +29,16 @@ def test_bench_json_contract():
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["unit"] == "MLUPS" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3
+    # everything the device did before the declared warm-up is in the line (VERDICT r3 item 3b / ADVICE r3)
+    assert d["preheat_steps"] >= 0 and d["preheat_ms"] >= 0 and isinstance(d["preheat_what"], str)
+    if d["config"]["fuse_steps"]:
+        assert d["preheat_steps"] >= 44 and d["preheat_ms"] > 0
+    assert "custom workload" in d["config"]["workload"] and "BASELINE configs[2]:" not in d["config"]["workload"]
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    # (k_step is HBM-bound, the marching kernels are bound by their vector instructions; this lattice sits at the edge of the automatic choice)
-    assert r["bound"] == ("valu" if d["config"]["fuse_steps"] else "hbm") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # `bound` follows from fractions MEASURED in the session; with --pmc-traffic 0 nothing is measured: the SURVEY's roof, no vector-ALU figure
+    assert r["bound"] == "hbm" and r["valu_busy_frac"] is None and r["valu"] is None and r["unit"] == "GB/s" and r["peak"] == 8000.0
     # (--pmc-traffic 0 and) no rocprofv3 counter entry exists for this lattice: `frac` is null, never the effective figure
     assert r["frac"] is None and r["achieved"] is None and r["traffic"] is None
     assert 0 < r["compulsory_frac"] <= 1.0 and abs(r["compulsory_frac"] - r["compulsory_gbps"] / r["peak"]) < 1e-12
@@ -47,7 +52,8 @@ def test_bench_json_contract():
 def test_bench_fused_flag_and_fp64():
     d = _run("--fuse", "2", "--dtype", "float32")           # forced on a small lattice: three steps per pass (the fp32 default)
     assert d["config"]["fuse_steps"] == 1 and d["config"]["fuse_depth"] == 3 and d["roofline"]["steps_per_launch"] == 3
-    assert d["roofline"]["bound"] == "valu" and d["roofline"]["frac"] is None and d["roofline"]["compulsory_frac"] <= 1.0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] is None and d["roofline"]["compulsory_frac"] <= 1.0
+    assert d["config"]["pass_depth"] == 3
     assert d["config"]["single_steps"] == 0                 # warm-up 3 = one pass, 20 timed steps = 3 x 6 + 2: no single step
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 3 * 72 * 1024 * 512
     d = _run("--fuse", "2", "--fuse-depth", "2", "--dtype", "float32")
@@ -68,6 +74,11 @@ def test_bench_measures_its_traffic_in_the_same_session():
     r = d["roofline"]
     assert r["frac"] is not None and 0.05 < r["frac"] <= 1.0, r
     assert "this session" in r["traffic_source"]["measured"]
+    # the SQ group of the third child run: a measured vector-ALU fraction, and `bound` = the larger of the two measured fractions
+    v = r["valu"]
+    assert v is not None and 0.02 < r["valu_busy_frac"] <= 2.0 and r["valu_busy_frac"] == v["valu_busy_frac"], r
+    assert 0 < v["valu_active_per_wave"] <= 1.0 and 0 <= v["waves_waiting_frac"] <= 1.0 and v["SQ_ACTIVE_INST_VALU"] > 0
+    assert r["bound"] == ("valu" if r["valu_busy_frac"] > r["frac"] else "hbm")
     # a four-step pass over 1024 x 512 fp32 moves at least one lattice read + one lattice write, and far less than four single steps
     assert 72 * 1024 * 512 <= r["traffic"] <= 2.5 * 72 * 1024 * 512, r["traffic"]
 
@@ -95,3 +106,23 @@ def test_bench_local_slabs_and_dat(tmp_path):
     d = _run("--local-slabs", "4", "--halo", "8", "--fuse", "2")
     ls = d["local_slabs"]
     assert len(ls["device_ms_per_step"]) == 4 and ls["one_slab_alone_ms_per_step"] > 0 and d["config"]["slabs"] == 4
+    # the per-rank report an N-GPU line carries (`ranks`), here from the in-process transport
+    assert [r["rank"] for r in d["ranks"]] == [0, 1, 2, 3]
+    for r in d["ranks"]:
+        for key in ("comm_ranks", "device_ms", "exchanges", "exchange_ms_each", "interior_ms_each", "exchange_exposed_ms_each", "exchange_hidden_frac",
+                    "fuse_depth", "pass_depth", "passes", "single_steps", "agree_checks", "chain_downgrades", "x0", "width"):
+            assert key in r, key
+        assert r["exchanges"] >= 1 and r["exchange_ms_each"] > 0 and r["chain_downgrades"] == 0 and r["agree_checks"] >= 1
+
+
+def test_bench_config_flag_runs_each_baseline_configuration_on_its_own_parameters():
+    """--config N: BASELINE.json's configurations on their OWN shape / AoA / tau / dtype / lattice; cfg 0 and cfg 4 here."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "0", "--cpu-steps", "0", "--pmc-traffic", "0", "--steps", "40", "--warmup", "8"],
+                         capture_output=True, text=True, timeout=600, check=True)
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert "BASELINE configs[0]" in d["config"]["workload"] and "NACA0012 256x128 float32" in d["config"]["workload"] and d["config"]["solid_sites"] == 1566
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--cpu-steps", "0", "--pmc-traffic", "0", "--steps", "24", "--warmup", "8"],
+                         capture_output=True, text=True, timeout=600, check=True)
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert "BASELINE configs[4]" in d["config"]["workload"] and "tau=0.5004007" in d["config"]["workload"] and d["dtype"] == "f64"
+    assert d["config"]["solid_sites"] == 405515 and d["config"]["nx"] == 4096 and d["config"]["ny"] == 2048
