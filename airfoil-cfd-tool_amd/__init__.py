@@ -4,7 +4,7 @@
 Import as ``airfoil_cfd_tool_amd`` (the directory name carries a hyphen; the
 sibling ``airfoil_cfd_tool_amd/`` package forwards here).
 """
-from . import geometry, datfile  # noqa: F401
+from . import geometry, datfile, compose  # noqa: F401
 from .datfile import DatParseError, load_dat, parse_dat_file, detect_and_merge_sections  # noqa: F401
 from ._capi import Engine, WTError, load_library, LIB_PATH  # noqa: F401
 from .windtunnel import (WindTunnel, build_lbm_component, Stats, stall_label, tau_from_reynolds,  # noqa: F401

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+from typing import Optional
 from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p
 
 import numpy as np
@@ -25,7 +26,8 @@ EXPORTS = (
     "wt_set_option", "wt_get_option",
     "wt_comm_unique_id", "wt_comm_init_rank", "wt_comm_selftest", "wt_link_local", "wt_step_group", "wt_step_group_timed",
     "wt_set_mask", "wt_init_equilibrium", "wt_step", "wt_step_timed", "wt_plan_steps", "wt_read_f", "wt_write_f",
-    "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_clamp_events", "wt_field", "wt_render_rgba", "wt_advect_tracers", "wt_sync",
+    "wt_read_macro", "wt_reduce_ranges", "wt_forces", "wt_clamp_events", "wt_field", "wt_render_rgba", "wt_advect_tracers",
+    "wt_canvas_stroke", "wt_canvas_compose", "wt_sync",
 )
 
 
@@ -95,6 +97,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         "wt_render_rgba": ([H, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p], c_int),
         "wt_advect_tracers": ([H, c_int, c_void_p, c_void_p, c_double, c_double, c_double, c_double, c_double, c_double,
                                c_void_p, c_void_p, c_void_p, c_void_p], c_int),
+        "wt_canvas_stroke": ([H, c_int, c_int, c_int, c_void_p], c_int),
+        "wt_canvas_compose": ([H, c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                               c_void_p], c_int),
         "wt_sync": ([H], c_int),
     }
     for name, (argtypes, restype) in sig.items():
@@ -295,6 +300,37 @@ class Engine:
                                            float(u0), dx0, dx1, dy0, dy1, xn.ctypes.data_as(c_void_p),
                                            yn.ctypes.data_as(c_void_p), sp.ctypes.data_as(c_void_p), ok.ctypes.data_as(c_void_p)))
         return xn, yn, sp, ok.astype(bool)
+
+    # -- the page's canvas on the device (csrc/canvas.hpp) --
+    def canvas_stroke(self, scale: int, fade: int, seg: Optional[np.ndarray] = None) -> None:
+        """Particle layer: fade (0 none / 1 fade / 2 clear), then stroke seg[n][8] = x0, y0, x1, y1 (canvas px), samples, r, g, b in order."""
+        if seg is None or len(seg) == 0:
+            _check(self._lib.wt_canvas_stroke(self._h, int(scale), int(fade), 0, None))
+            return
+        a = np.ascontiguousarray(seg, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != 8:
+            raise ValueError("seg must be [n][8]")
+        _check(self._lib.wt_canvas_stroke(self._h, int(scale), int(fade), int(a.shape[0]), a.ctypes.data_as(c_void_p)))
+
+    def canvas_compose(self, scale: int, mode: int, u0: float, max_s: float, cp_min: float, cp_max: float, vort_scale: float,
+                       poly_xy: np.ndarray, bar_rgb: np.ndarray, text_alpha: Optional[np.ndarray], use_trails: bool) -> np.ndarray:
+        """One frame of the page's canvas, RGBA8 [360*scale][680*scale][4], top row first; text_alpha None = the previous call's map."""
+        s = int(scale)
+        poly = np.ascontiguousarray(poly_xy, dtype=np.float64).reshape(-1, 2)
+        bar = np.ascontiguousarray(bar_rgb, dtype=np.uint8)
+        if bar.shape != (308 * s, 3):
+            raise ValueError(f"bar_rgb must be [{308 * s}][3]")
+        txt = None
+        if text_alpha is not None:
+            txt = np.ascontiguousarray(text_alpha, dtype=np.float32)
+            if txt.shape != (360 * s, 680 * s):
+                raise ValueError(f"text_alpha must be [{360 * s}][{680 * s}]")
+        out = np.empty((360 * s, 680 * s, 4), dtype=np.uint8)
+        _check(self._lib.wt_canvas_compose(self._h, s, int(mode), float(u0), float(max_s), float(cp_min), float(cp_max), float(vort_scale),
+                                           poly.ctypes.data_as(c_void_p), int(poly.shape[0]), bar.ctypes.data_as(c_void_p),
+                                           None if txt is None else txt.ctypes.data_as(c_void_p), 1 if use_trails else 0,
+                                           out.ctypes.data_as(c_void_p)))
+        return out
 
     def sync(self) -> None:
         _check(self._lib.wt_sync(self._h))

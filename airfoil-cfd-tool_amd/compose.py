@@ -76,12 +76,15 @@ _GLYPHS = {
 class Canvas:
     """RGB float canvas (0..255) with the few primitives the page uses."""
 
-    def __init__(self, scale: int = 1):
+    def __init__(self, scale: int = 1, alloc: bool = True):
+        """alloc=False: geometry only (w2c) — what a stroke onto a device-resident layer needs."""
         self.s = int(scale)
         self.w, self.h = W0 * self.s, H0 * self.s
         self.px, self.py, self.pw, self.ph = PX0 * self.s, PY0 * self.s, PW0 * self.s, PH0 * self.s
-        self.rgb = np.empty((self.h, self.w, 3), dtype=np.float64)
-        self.rgb[:] = BG
+        self.rgb = None
+        if alloc:
+            self.rgb = np.empty((self.h, self.w, 3), dtype=np.float64)
+            self.rgb[:] = BG
         self._cov = None
 
     # world -> canvas (html:810-811); y_half = half-height of the tunnel window
@@ -201,13 +204,9 @@ class TrailLayer:
     def stroke(self, canvas: Canvas, seg: np.ndarray, t: np.ndarray, y_half: float) -> None:
         if len(seg) == 0:
             return
-        x0, y0 = canvas.w2c(seg[:, 0], seg[:, 1], y_half)
-        x1, y1 = canvas.w2c(seg[:, 2], seg[:, 3], y_half)
-        base = cmap(t)
-        lum = (0.55 + np.asarray(t) * 0.45)[:, None]
-        col = np.rint(base * 0.4 + 255.0 * 0.6 * lum)                  # html:798
         # segments are a few pixels long: sample them densely and splat with a small round brush
-        n = np.maximum(2, np.ceil(np.hypot(x1 - x0, y1 - y0) * 2).astype(int) + 1)
+        rec = stroke_records(canvas, seg, t, y_half)
+        x0, y0, x1, y1, n, col = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 4].astype(int), rec[:, 5:8]
         r = 1.1 * self.s / 2.0 + 0.5
         for i in range(len(seg)):
             ts = np.linspace(0.0, 1.0, int(n[i]))
@@ -227,6 +226,71 @@ class TrailLayer:
         canvas.rgb = canvas.rgb * (1 - self.a[..., None]) + self.rgb        # drawImage(pcv, 0, 0), html:924
 
 
+def stroke_records(canvas: Canvas, seg: np.ndarray, t: np.ndarray, y_half: float) -> np.ndarray:
+    """The strokes of one frame as TrailLayer.stroke splats them, [n][8] = x0, y0, x1, y1 (canvas pixels), points sampled along the segment,
+    r, g, b (html:796-798) — the host layer loops over them, the device layer (wt_canvas_stroke) takes the array."""
+    if len(seg) == 0:
+        return np.zeros((0, 8))
+    x0, y0 = canvas.w2c(seg[:, 0], seg[:, 1], y_half)
+    x1, y1 = canvas.w2c(seg[:, 2], seg[:, 3], y_half)
+    base = cmap(t)
+    lum = (0.55 + np.asarray(t) * 0.45)[:, None]
+    col = np.rint(base * 0.4 + 255.0 * 0.6 * lum)                      # html:798
+    n = np.maximum(2, np.ceil(np.hypot(x1 - x0, y1 - y0) * 2).astype(int) + 1)
+    return np.column_stack([x0, y0, x1, y1, n.astype(np.float64), col])
+
+
+class DeviceTrailLayer:
+    """The particle canvas `pcv` kept on the GPU (wt_canvas_stroke): the interface of TrailLayer that Tracers.draw uses — fade(), stroke() —
+    with the blending done per pixel on the device instead of per particle in Python (86 ms -> well under a millisecond per frame)."""
+
+    def __init__(self, engine, scale: int = 1):
+        self.engine, self.s = engine, int(scale)
+        self._geom = Canvas(self.s, alloc=False)
+        self._fade = 0
+        engine.canvas_stroke(self.s, 2)                                # clear
+
+    def fade(self) -> None:
+        self._fade = 1                                                 # applied by the next stroke, in the same kernel
+
+    def stroke(self, canvas, seg: np.ndarray, t: np.ndarray, y_half: float) -> None:
+        self.engine.canvas_stroke(self.s, self._fade, stroke_records(self._geom, seg, t, y_half))
+        self._fade = 0
+
+
+def bar_rows(field_mode: int, scale: int) -> np.ndarray:
+    """drawBar's rows (html:830-848): row i = map(1 - i/bh) truncated like `r|0`; uint8 [PH0 * scale][3]."""
+    bh = PH0 * int(scale)
+    i = np.arange(bh, dtype=np.float64)
+    rows = cmap_cp(1 - i / bh) if field_mode == 1 else cmap_vort(1 - 2 * i / bh) if field_mode == 2 else cmap(1 - i / bh)
+    return rows.astype(int).astype(np.uint8)
+
+
+def label_calls(cv: Canvas, aoa_deg: float, field_mode: int, y_half: float):
+    """The page's text (html:830-860) as (string, x, baseline, alpha, align, px) — drawn by compose() and by text_alpha_map() alike."""
+    bx, by, bw, bh = cv.w - 32 * cv.s, cv.py, 10 * cv.s, cv.ph
+    top = "+Cp" if field_mode == 1 else "CCW" if field_mode == 2 else "fast"
+    bot = "-Cp" if field_mode == 1 else "CW" if field_mode == 2 else "slow"
+    calls = [(top, bx + bw + 3 * cv.s, by + 9 * cv.s, 0.55, "left", 10), (bot, bx + bw + 3 * cv.s, by + bh - 1 * cv.s, 0.55, "left", 10)]
+    for xv in (0.0, 0.5, 1.0):
+        x, _ = cv.w2c(xv, 0.0, y_half)
+        calls.append((f"{xv:.1f}", float(x), cv.h - 8 * cv.s, 0.4, "center", 10))
+    for yv in (-0.4, 0.0, 0.4):
+        _, y = cv.w2c(0.0, yv, y_half)
+        calls.append((f"{yv:.1f}", cv.px - 6 * cv.s, float(y) + 3 * cv.s, 0.4, "right", 10))
+    calls.append((f"α = {aoa_deg:.1f}°", cv.px + 8 * cv.s, cv.py + 16 * cv.s, 0.75, "left", 12))
+    return calls
+
+
+def text_alpha_map(scale: int, aoa_deg: float, field_mode: int, y_half: float) -> np.ndarray:
+    """Alpha of the (white) labels at every canvas pixel, float32 [H][W] — what wt_canvas_compose blends last.  The strings do not overlap."""
+    probe = Canvas(scale, alloc=False)
+    probe.rgb = np.zeros((probe.h, probe.w, 3), dtype=np.float64)     # blending white (1, 1, 1) onto 0 leaves exactly the alpha
+    for s, x, y, alpha, align, px in label_calls(probe, aoa_deg, field_mode, y_half):
+        probe.text(s, x, y, (1.0, 1.0, 1.0), alpha, align, px)
+    return probe.rgb[..., 0].astype(np.float32)
+
+
 def compose(field_rgba_top_first: np.ndarray, xp: Sequence[float], yp: Sequence[float], aoa_deg: float, field_mode: int,
             y_half: float, trails: Optional[TrailLayer] = None, scale: int = 1) -> np.ndarray:
     """One frame of the page's canvas (html:919-927): RGBA8 [360*scale][680*scale][4], top row first."""
@@ -240,21 +304,11 @@ def compose(field_rgba_top_first: np.ndarray, xp: Sequence[float], yp: Sequence[
     cv.polyline(fx, fy, FOIL_STROKE[:3], FOIL_STROKE[3], 1.4 * cv.s, closed=True)
     # drawBar (html:830-848): bh rows, row i = map(1 - i/bh) truncated like `r|0`; each 1.5-px rect is overdrawn by the next
     bx, by, bw, bh = cv.w - 32 * cv.s, cv.py, 10 * cv.s, cv.ph
-    i = np.arange(bh, dtype=np.float64)
-    rows = (cmap_cp(1 - i / bh) if field_mode == 1 else cmap_vort(1 - 2 * i / bh) if field_mode == 2 else cmap(1 - i / bh)).astype(int)
+    rows = bar_rows(field_mode, cv.s).astype(np.float64)
     cv.rgb[by:by + bh, bx:bx + bw] = rows[:, None, :]
     if by + bh < cv.h:      # the last rect's lower half pixel
         cv.rgb[by + bh, bx:bx + bw] = cv.rgb[by + bh, bx:bx + bw] * 0.5 + rows[-1] * 0.5
-    top = "+Cp" if field_mode == 1 else "CCW" if field_mode == 2 else "fast"
-    bot = "-Cp" if field_mode == 1 else "CW" if field_mode == 2 else "slow"
-    cv.text(top, bx + bw + 3 * cv.s, by + 9 * cv.s, (255, 255, 255), 0.55)
-    cv.text(bot, bx + bw + 3 * cv.s, by + bh - 1 * cv.s, (255, 255, 255), 0.55)
-    # drawLabels (html:850-860)
-    for xv in (0.0, 0.5, 1.0):
-        x, _ = cv.w2c(xv, 0.0, y_half)
-        cv.text(f"{xv:.1f}", float(x), cv.h - 8 * cv.s, (255, 255, 255), 0.4, "center")
-    for yv in (-0.4, 0.0, 0.4):
-        _, y = cv.w2c(0.0, yv, y_half)
-        cv.text(f"{yv:.1f}", cv.px - 6 * cv.s, float(y) + 3 * cv.s, (255, 255, 255), 0.4, "right")
-    cv.text(f"α = {aoa_deg:.1f}°", cv.px + 8 * cv.s, cv.py + 16 * cv.s, (255, 255, 255), 0.75, "left", px=12)
+    # drawLabels (html:850-860) and the bar's captions
+    for s_, x, y, alpha, align, px in label_calls(cv, aoa_deg, field_mode, y_half):
+        cv.text(s_, x, y, (255, 255, 255), alpha, align, px)
     return cv.to_rgba8()

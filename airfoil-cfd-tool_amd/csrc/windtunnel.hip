@@ -22,6 +22,7 @@
 #include "step_march.hpp"
 #include "step_march3.hpp"
 #include "step_chain.hpp"
+#include "canvas.hpp"
 #ifndef WT_LOAD_AUX
 #define WT_LOAD_AUX 2
 #endif
@@ -168,6 +169,15 @@ struct wt_handle {
     bool clk_on = false;
     size_t clk_off = 0;
     long wave_slots = 0;                 // resident marching waves of the device: CUs x 4 SIMDs x 2 (x WT_MARCH_WAVES / 2 in an experiment build)
+    // the page's canvas on the device (canvas.hpp): particle layer, text alphas, polygon / bar / segment staging, the RGBA8 result
+    int cv_scale = 0;
+    double4 *cv_layer = nullptr;
+    float *cv_text = nullptr;
+    bool cv_text_set = false;
+    uchar4 *cv_out = nullptr;
+    double *cv_small = nullptr;          // polygon (up to CV_MAX_POLY points) + bar rows
+    double *cv_seg = nullptr;
+    size_t cv_seg_cap = 0;
     int chain_downgrades = 0;            // groups of four units whose chain flags failed sanitize_chain_plan (option "chain_downgrades"; 0 by construction)
     // cross-rank agreement (slab handles): everything that decides the sequence of passes / single steps / refreshes must be the same on every
     // slab of a tunnel — checked, not assumed (agree_rccl / agree_local)
@@ -377,6 +387,11 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->d_nbad) (void)hipFree(h->d_nbad);
     if (h->d_agree) (void)hipFree(h->d_agree);
+    if (h->cv_layer) (void)hipFree(h->cv_layer);
+    if (h->cv_text) (void)hipFree(h->cv_text);
+    if (h->cv_out) (void)hipFree(h->cv_out);
+    if (h->cv_small) (void)hipFree(h->cv_small);
+    if (h->cv_seg) (void)hipFree(h->cv_seg);
     for (hipEvent_t e : h->xt_ev) if (e) (void)hipEventDestroy(e);
     if (h->partials) (void)hipFree(h->partials);
     if (h->partials_host) (void)hipHostFree(h->partials_host);
@@ -2193,6 +2208,111 @@ extern "C" int wt_advect_tracers(wt_handle *h, int n, const double *x, const dou
     HIP_TRY(hipMemcpyAsync(y_new, oy, nd, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipMemcpyAsync(speed, os, nd, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipMemcpyAsync(ok, dok, (size_t)n, hipMemcpyDeviceToHost, h->s_compute));
+    HIP_TRY(hipStreamSynchronize(h->s_compute));
+    return WT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// the page's canvas (canvas.hpp)
+// ------------------------------------------------------------------------------------------
+static const int CV_MAX_POLY = 4096;
+static const int CV_MAX_SCALE = 8;
+
+static int canvas_ensure(wt_handle *h, int scale)
+{
+    if (scale < 1 || scale > CV_MAX_SCALE) return fail(WT_ERR_ARG, "canvas scale must be 1 .. %d", CV_MAX_SCALE);
+    if (h->nranks > 1) return fail(WT_ERR_STATE, "the canvas needs the whole lattice on one handle");
+    if (h->cv_scale == scale) return WT_OK;
+    const CanvasDims d = canvas_dims(scale);
+    const size_t npx = (size_t)d.w * d.h;
+    if (h->cv_layer) { HIP_TRY(hipFree(h->cv_layer)); h->cv_layer = nullptr; }
+    if (h->cv_text) { HIP_TRY(hipFree(h->cv_text)); h->cv_text = nullptr; }
+    if (h->cv_out) { HIP_TRY(hipFree(h->cv_out)); h->cv_out = nullptr; }
+    h->cv_scale = 0;
+    HIP_TRY(hipMalloc((void **)&h->cv_layer, npx * sizeof(double4)));
+    HIP_TRY(hipMalloc((void **)&h->cv_text, npx * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&h->cv_out, npx * sizeof(uchar4)));
+    if (!h->cv_small) HIP_TRY(hipMalloc((void **)&h->cv_small, ((size_t)2 * CV_MAX_POLY + (size_t)3 * 308 * CV_MAX_SCALE / 8 + 64) * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(h->cv_layer, 0, npx * sizeof(double4), h->s_compute));
+    HIP_TRY(hipMemsetAsync(h->cv_text, 0, npx * sizeof(float), h->s_compute));
+    h->cv_text_set = false;
+    h->cv_scale = scale;
+    return WT_OK;
+}
+
+extern "C" int wt_canvas_stroke(wt_handle *h, int scale, int fade, int n, const double *seg)
+{
+    WT_TRY(check_handle(h));
+    if (fade < 0 || fade > 2 || n < 0 || (n > 0 && !seg)) return fail(WT_ERR_ARG, "bad stroke arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    WT_TRY(canvas_ensure(h, scale));
+    const CanvasDims d = canvas_dims(scale);
+    if (n > 0) {
+        const size_t bytes = (size_t)n * 8 * sizeof(double);
+        if ((size_t)n > h->cv_seg_cap) {
+            if (h->cv_seg) { HIP_TRY(hipFree(h->cv_seg)); h->cv_seg = nullptr; h->cv_seg_cap = 0; }
+            const size_t cap = (size_t)n + (size_t)n / 2 + 256;
+            HIP_TRY(hipMalloc((void **)&h->cv_seg, cap * 8 * sizeof(double)));
+            h->cv_seg_cap = cap;
+        }
+        for (int i = 0; i < n; i++)
+            if (!(seg[8 * i + 4] >= 2.0 && seg[8 * i + 4] <= 65536.0)) return fail(WT_ERR_ARG, "segment %d: sample count out of range", i);
+        HIP_TRY(hipMemcpyAsync(h->cv_seg, seg, bytes, hipMemcpyHostToDevice, h->s_compute));
+    }
+    if (fade == 0 && n == 0) return WT_OK;
+    hipLaunchKernelGGL(k_canvas_stroke, dim3((unsigned)((d.w + 7) / 8), (unsigned)((d.h + 7) / 8)), dim3(64), 0, h->s_compute, h->cv_layer, d, fade, n,
+                       (const double *)h->cv_seg);
+    HIP_TRY(hipGetLastError());
+    if (n > 0) HIP_TRY(hipStreamSynchronize(h->s_compute));       // the caller's segment array may go away
+    return WT_OK;
+}
+
+template <typename T>
+static void canvas_launch(wt_handle *h, const CanvasArgs &a, int mode, double u0, double max_s, double cp_min, double cp_max, double vs)
+{
+    FieldParams<T> fp;
+    fp.U0 = (T)u0; fp.maxS = (T)max_s; fp.cpMin = (T)cp_min; fp.cpMax = (T)cp_max; fp.vortScale = (T)vs; fp.mode = mode;
+    hipLaunchKernelGGL(k_canvas_compose<T>, dim3((unsigned)((a.d.w + 15) / 16), (unsigned)((a.d.h + 15) / 16)), dim3(256), 0, h->s_compute,
+                       reinterpret_cast<const T *>(h->macro), (const uint8_t *)h->mask, h->g, fp, a, h->cv_out);
+}
+
+extern "C" int wt_canvas_compose(wt_handle *h, int scale, int mode, double u0, double max_s, double cp_min, double cp_max, double vort_scale,
+                                 const double *poly_xy, int npoly, const uint8_t *bar_rgb, const float *text_alpha, int use_trails,
+                                 uint8_t *rgba_out)
+{
+    WT_TRY(check_handle(h));
+    if (!rgba_out || !bar_rgb) return fail(WT_ERR_ARG, "null argument");
+    if (mode < 0 || mode > 2) return fail(WT_ERR_ARG, "mode must be 0 (speed), 1 (cp) or 2 (vort)");
+    if (npoly < 0 || npoly > CV_MAX_POLY || (npoly > 0 && !poly_xy)) return fail(WT_ERR_ARG, "polygon of 0 .. %d points expected", CV_MAX_POLY);
+    if (!h->inited || !h->mask_set) return fail(WT_ERR_STATE, "state or mask missing");
+    if (h->macro_stale) return fail(WT_ERR_STATE, "wt_write_f replaced the populations: (rho,ux,uy) are emitted by the next wt_step");
+    HIP_TRY(hipSetDevice(h->device));
+    WT_TRY(canvas_ensure(h, scale));
+    const CanvasDims d = canvas_dims(scale);
+    const size_t npx = (size_t)d.w * d.h;
+    CanvasArgs a;
+    a.d = d;
+    a.layer = use_trails ? h->cv_layer : nullptr;
+    a.npoly = npoly;
+    a.poly = h->cv_small;
+    a.bar = reinterpret_cast<const uint8_t *>(h->cv_small + 2 * CV_MAX_POLY);
+    a.foil_r = 1.4 * scale / 2.0 + 0.5;
+    a.pbx0 = a.pby0 = 1e300; a.pbx1 = a.pby1 = -1e300;
+    for (int i = 0; i < npoly; i++) {
+        a.pbx0 = std::min(a.pbx0, poly_xy[2 * i]); a.pbx1 = std::max(a.pbx1, poly_xy[2 * i]);
+        a.pby0 = std::min(a.pby0, poly_xy[2 * i + 1]); a.pby1 = std::max(a.pby1, poly_xy[2 * i + 1]);
+    }
+    if (npoly > 0) HIP_TRY(hipMemcpyAsync(h->cv_small, poly_xy, (size_t)npoly * 2 * sizeof(double), hipMemcpyHostToDevice, h->s_compute));
+    HIP_TRY(hipMemcpyAsync(h->cv_small + 2 * CV_MAX_POLY, bar_rgb, (size_t)d.ph * 3, hipMemcpyHostToDevice, h->s_compute));
+    if (text_alpha) {
+        HIP_TRY(hipMemcpyAsync(h->cv_text, text_alpha, npx * sizeof(float), hipMemcpyHostToDevice, h->s_compute));
+        h->cv_text_set = true;
+    }
+    a.text = h->cv_text_set ? h->cv_text : nullptr;
+    if (h->dtype == WT_F32) canvas_launch<float>(h, a, mode, u0, max_s, cp_min, cp_max, vort_scale);
+    else canvas_launch<double>(h, a, mode, u0, max_s, cp_min, cp_max, vort_scale);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgba_out, h->cv_out, npx * 4, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     return WT_OK;
 }

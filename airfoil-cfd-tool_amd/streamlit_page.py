@@ -93,7 +93,7 @@ def build_lbm_component(coords_after, airfoil_name: str = "", *, nx: int = 1024,
             tracers.resize(ntrails)
         layer = st.session_state.get("wt_amd_trails")
         if layer is None or layer.s != scale:
-            layer = st.session_state["wt_amd_trails"] = TrailLayer(scale)
+            layer = st.session_state["wt_amd_trails"] = wt.trail_layer(scale)      # on the GPU for a whole-lattice tunnel
         canvas = st.empty()                                                          # the <canvas> of the component
         slots = [c.empty() for c in st.columns(4)]
         return tracers, layer, canvas, slots

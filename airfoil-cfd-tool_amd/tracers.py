@@ -77,7 +77,7 @@ class Tracers:
         from .compose import Canvas
         seg, t = self.step(dt)
         layer.fade()
-        layer.stroke(Canvas(layer.s), seg, t, self.window[3])
+        layer.stroke(Canvas(layer.s, alloc=False), seg, t, self.window[3])
         return seg, t
 
     # html:780-808

@@ -218,14 +218,39 @@ class WindTunnel:
         """Half-height of the tunnel window in chord units (html:73 on 2:1 lattices; square cells otherwise)."""
         return self.y_half if self.y_half is not None else geo.domain_y_half(self.nx, self.ny)
 
+    def _canvas_on_device(self, trails) -> bool:
+        """The device canvas (wt_canvas_compose) serves whole-lattice handles; a host-side compose.TrailLayer keeps the NumPy compositor."""
+        from . import compose
+        return (hasattr(self.engine, "canvas_compose") and getattr(self.engine, "nranks", 1) == 1
+                and (trails is None or isinstance(trails, compose.DeviceTrailLayer)))
+
+    def trail_layer(self, scale: int = 1):
+        """A particle layer for Tracers.draw: on the GPU where the canvas is composited there, else the NumPy one."""
+        from . import compose
+        return compose.DeviceTrailLayer(self.engine, scale) if self._canvas_on_device(None) else compose.TrailLayer(scale)
+
     def compose_frame(self, field: Optional[str] = None, trails=None, scale: int = 1) -> np.ndarray:
         """The page's whole canvas for the current state (html:919-927): field image scaled into the plot rectangle,
-        tracer strokes (a compose.TrailLayer, see tracers.Tracers.draw), foil fill + outline, colour bar with captions,
-        axis ticks and the angle read-out.  RGBA8 [360*scale][680*scale][4], top row first."""
+        tracer strokes (a particle layer, see trail_layer / tracers.Tracers.draw), foil fill + outline, colour bar with captions,
+        axis ticks and the angle read-out.  RGBA8 [360*scale][680*scale][4], top row first.  Composited on the GPU per canvas pixel
+        (csrc/canvas.hpp) unless `trails` is a host-side compose.TrailLayer or the tunnel is sharded: then by the NumPy compositor."""
         from . import compose
         mode = FIELD_MODES[field or self.field]
-        return compose.compose(self.render_rgba(field)[::-1], self.geometry.xp, self.geometry.yp, self.aoa_deg, mode,
-                               self.y_half_world(), trails=trails, scale=scale)
+        if not self._canvas_on_device(trails):
+            return compose.compose(self.render_rgba(field)[::-1], self.geometry.xp, self.geometry.yp, self.aoa_deg, mode,
+                                   self.y_half_world(), trails=trails, scale=scale)
+        if trails is not None and (trails.s != int(scale) or trails.engine is not self.engine):
+            raise ValueError("the particle layer belongs to another canvas (scale or tunnel)")
+        cv = compose.Canvas(scale, alloc=False)
+        fx, fy = cv.w2c(self.geometry.xp, self.geometry.yp, self.y_half_world())
+        key = (int(scale), mode, float(self.aoa_deg), float(self.y_half_world()))
+        text = None
+        if key != getattr(self, "_canvas_text_key", None):             # the labels change with the angle, the field and the scale only
+            text = compose.text_alpha_map(scale, self.aoa_deg, mode, self.y_half_world())
+        img = self.engine.canvas_compose(scale, mode, self.u0, self.max_s, self.cp_min, self.cp_max, VORT_SCALE, np.column_stack([fx, fy]),
+                                         compose.bar_rows(mode, scale), text, trails is not None)
+        self._canvas_text_key = key
+        return img
 
     def save_png(self, path: Optional[str] = None, field: Optional[str] = None, composite: bool = True, trails=None,
                  scale: int = 1) -> str:

@@ -258,6 +258,24 @@ WT_API int wt_advect_tracers(wt_handle *h, int n, const double *x, const double 
                       double dx0, double dx1, double dy0, double dy1,
                       double *x_new, double *y_new, double *speed, uint8_t *ok);
 
+/* ---- the page's 2-D canvas on the device (csrc/canvas.hpp) ---------------------------------
+ * Replaces the canvas drawing of frame() (html:919-927) for a whole-lattice handle: 680*scale x 360*scale pixels, top row first.
+ * Round 3 composited the frame with NumPy on the host (compose.py, which stays as the host path and as this one's test reference); the
+ * page's loop then ran at 9 frames per second at any lattice size, all of it host time (profiles/r04_a_frame_loop_host_canvas.txt).
+ *
+ * wt_canvas_stroke: the particle layer `pcv` (html:780-808), kept in device memory per handle.  fade: 0 none, 1 the frame's
+ *   destination-out fade (x 0.945), 2 clear.  Then n segments are stroked in order: seg[i] = {x0, y0, x1, y1 in canvas pixels, ns = points
+ *   sampled along the segment (>= 2), r, g, b = the stroke's colour 0..255}; a round brush of radius 1.1 scale / 2 + 0.5, alpha 0.75.
+ * wt_canvas_compose: one frame — background, the field image of wt_render_rgba resampled into the plot rectangle (drawImage, html:923),
+ *   the particle layer when use_trails != 0, the foil polygon poly_xy[npoly][2] (canvas pixels) filled (#0d1018) and outlined (html:815-828),
+ *   the colour bar bar_rgb[308*scale][3] (html:830-848) and the labels: text_alpha[360*scale][680*scale] = alpha of the white text at every
+ *   pixel (0 = none), or NULL to keep the map of the previous call (it changes with the angle and the field only).  mode .. vort_scale as
+ *   in wt_render_rgba.  rgba_out: [360*scale][680*scale][4]. */
+WT_API int wt_canvas_stroke(wt_handle *h, int scale, int fade, int n, const double *seg);
+WT_API int wt_canvas_compose(wt_handle *h, int scale, int mode, double u0, double max_s, double cp_min, double cp_max, double vort_scale,
+                             const double *poly_xy, int npoly, const uint8_t *bar_rgb, const float *text_alpha, int use_trails,
+                             uint8_t *rgba_out);
+
 WT_API int wt_sync(wt_handle *h);
 
 #ifdef __cplusplus

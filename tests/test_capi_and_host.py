@@ -36,7 +36,7 @@ def test_dynamic_symbol_table_is_the_header(pkg):
     out = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], check=True, capture_output=True, text=True).stdout
     syms = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
     assert syms == _declared_exports(), sorted(set(syms) ^ set(_declared_exports()))
-    assert len(syms) == 30
+    assert len(syms) == 32
 
 
 def test_streamlit_image_keyword_follows_the_installed_version():

@@ -180,3 +180,55 @@ def test_composited_png_of_a_running_tunnel(pkg, tmp_path):
         assert struct.unpack(">II", raw[16:24]) == (680, 360)
         bare = wt.save_png(str(tmp_path / "bare.png"), composite=False)
         assert struct.unpack(">II", open(bare, "rb").read()[16:24]) == (320, 160)
+
+
+@pytest.mark.parametrize("dtype,nx,ny,field,scale", [("float32", 320, 160, "speed", 1), ("float32", 1024, 512, "vort", 1),
+                                                     ("float64", 640, 320, "cp", 1), ("float32", 320, 160, "speed", 2)])
+def test_device_canvas_equals_the_numpy_compositor(pkg, dtype, nx, ny, field, scale):
+    """The page's canvas composited per pixel on the GPU (csrc/canvas.hpp: wt_canvas_stroke, wt_canvas_compose) against the NumPy compositor
+    of round 3 (compose.py), which draws by the same rules in the same arithmetic: field resampling, particle layer after 25 frames of
+    fading strokes, foil fill and outline, bar, labels.  The two differ by at most one level in a handful of pixels (libm vs device hypot
+    at rounding ties)."""
+    from airfoil_cfd_tool_amd.compose import DeviceTrailLayer, TrailLayer
+    from airfoil_cfd_tool_amd.tracers import Tracers
+    with pkg.WindTunnel(shape="naca4412", nx=nx, ny=ny, aoa_deg=9.0, dtype=dtype, field=field) as wt:
+        host_layer, dev_layer = TrailLayer(scale), wt.trail_layer(scale)
+        assert isinstance(dev_layer, DeviceTrailLayer)
+        tr_h, tr_d = Tracers(wt, n=700, seed=11), Tracers(wt, n=700, seed=11)        # the same particles twice: one per layer
+        for _ in range(25):
+            wt.frame(render=False)
+            sh, _ = tr_h.draw(host_layer, 16.0)
+            sd, _ = tr_d.draw(dev_layer, 16.0)
+            assert np.array_equal(sh, sd)
+        ref = wt.compose_frame(trails=host_layer, scale=scale)                       # host path (a compose.TrailLayer selects it)
+        img = wt.compose_frame(trails=dev_layer, scale=scale)                        # device path
+        assert img.shape == ref.shape == (360 * scale, 680 * scale, 4) and img.dtype == np.uint8
+        diff = np.abs(img.astype(int) - ref.astype(int))
+        assert diff.max() <= 1, (diff.max(), int((diff > 1).sum()))
+        assert (diff > 0).mean() < 2e-3, (diff > 0).mean()
+        assert (host_layer.a > 0.3).sum() > 200                                       # strokes exist in what was compared
+        # without a particle layer, and again after the angle changed (new labels, new polygon)
+        assert np.abs(wt.compose_frame(scale=scale).astype(int) - pkg.compose.compose(
+            wt.render_rgba()[::-1], wt.geometry.xp, wt.geometry.yp, wt.aoa_deg, pkg.FIELD_MODES[field], wt.y_half_world(), scale=scale).astype(int)).max() <= 1
+        wt.aoa_deg = -4.5
+        wt.frame(render=False)
+        a = wt.compose_frame(trails=dev_layer, scale=scale)
+        b = wt.compose_frame(trails=host_layer, scale=scale)
+        assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+
+
+def test_frame_loop_with_the_device_canvas_is_interactive(pkg):
+    """The page's loop (frame(), tracers, composited canvas) on the reference's own lattice: with the canvas on the device it runs far above
+    the 9 frames per second the NumPy compositor gave (profiles/r04_a_frame_loop_host_canvas.txt); asserted loosely: > 60 per second."""
+    import time
+    from airfoil_cfd_tool_amd.tracers import Tracers
+    with pkg.WindTunnel(shape="naca2412", nx=320, ny=160, aoa_deg=6.0) as wt:
+        layer = wt.trail_layer(1)
+        tr = Tracers(wt, seed=5)
+        for _ in range(10):
+            wt.frame(render=False); tr.draw(layer, 16.0); wt.compose_frame(trails=layer)
+        t0 = time.perf_counter()
+        for _ in range(60):
+            wt.frame(render=False); tr.draw(layer, 16.0); img = wt.compose_frame(trails=layer)
+        fps = 60 / (time.perf_counter() - t0)
+        assert img.shape == (360, 680, 4) and fps > 60, fps

@@ -4,7 +4,8 @@ reference's lattice (320x160, html:76), the build's page default (1024x512) and 
 device stepping, the small read-backs (ranges, forces), the RGBA read-back, the tracers (device advect + host bookkeeping + strokes) and the
 NumPy compositor.  VERDICT r3 item 7.
 
-    python tools/r4_frame_loop.py [frames]         -> one table per lattice on stdout (profiles/r04_frame_loop.txt)
+    python tools/r4_frame_loop.py [frames]         -> two tables per lattice on stdout (profiles/r04_*_frame_loop.txt): the host canvas of
+                                                      round 3 (compose.py) and the device canvas (csrc/canvas.hpp)
 """
 import os
 import sys
@@ -28,7 +29,7 @@ def timed(fn, sync):
 
 def run(nx, ny, frames, device_canvas):
     with pkg.WindTunnel(shape="naca2412", nx=nx, ny=ny, aoa_deg=6.0) as wt:
-        tracers, layer = Tracers(wt, seed=1), TrailLayer(1)
+        tracers, layer = Tracers(wt, seed=1), (wt.trail_layer(1) if device_canvas else TrailLayer(1))
         sync = wt.engine.sync
         for _ in range(12):                                          # warm-up: plan tuned, clocks up, first macro emitted
             wt.frame(render=False)
@@ -43,8 +44,8 @@ def run(nx, ny, frames, device_canvas):
             if wt.stat_counter % 3 == 0:
                 ms, _ = timed(wt.compute_forces, lambda: None); acc["forces"] += ms
             ms, _ = timed(lambda: tracers.draw(layer, 16.0), lambda: None); acc["tracers"] += ms
-            if device_canvas and hasattr(wt, "compose_frame_device"):
-                ms, _ = timed(lambda: wt.compose_frame_device(trails=layer), lambda: None); acc["compose"] += ms
+            if device_canvas:        # wt_canvas_compose: field colours, particle layer, foil, bar, labels per canvas pixel + the 1 MB read-back
+                ms, _ = timed(lambda: wt.compose_frame(trails=layer), lambda: None); acc["compose"] += ms
             else:
                 ms, img = timed(wt.render_rgba, lambda: None); acc["rgba"] += ms
                 from airfoil_cfd_tool_amd import compose
@@ -65,9 +66,8 @@ def run(nx, ny, frames, device_canvas):
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     for nx, ny in ((320, 160), (1024, 512), (4096, 2048)):
-        run(nx, ny, frames if nx < 4096 else max(10, frames // 3), False)
-        if hasattr(pkg.WindTunnel, "compose_frame_device"):
-            run(nx, ny, frames if nx < 4096 else max(10, frames // 3), True)
+        run(nx, ny, frames if nx < 4096 else max(10, frames // 3), False)      # round 3: NumPy compositor, per-particle strokes in Python
+        run(nx, ny, 4 * frames, True)                                          # the canvas on the device (csrc/canvas.hpp)
 
 
 if __name__ == "__main__":
