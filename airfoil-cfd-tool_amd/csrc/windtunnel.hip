@@ -178,6 +178,14 @@ struct wt_handle {
     double *cv_small = nullptr;          // polygon (up to CV_MAX_POLY points) + bar rows
     double *cv_seg = nullptr;
     size_t cv_seg_cap = 0;
+    // Trimmed ghost marching (slab handles, three / four steps per pass): a pass that starts with gv exact ghost columns and advances k steps
+    // leaves gv - k of them exact — marching the others is work whose result nobody may read.  One unit list per "exact ghost columns after
+    // the pass" (the kept plan's range shrunk at the slab's local edges), cut lazily with the kept plan's measured column costs.
+    struct TrimPlan { int v_after = -1; MarchUnit *d_units = nullptr; size_t cap = 0; int n_units = 0; bool valid = false; };
+    std::vector<TrimPlan> trim_plans;
+    std::vector<float> colw_kept;        // column-cost corrections of the plan tune_fuse_plan kept (empty: the modelled costs)
+    bool trim = true;                    // option "trim_ghosts"
+    long long trimmed_passes = 0;        // passes that marched a trimmed range (option "trimmed_passes")
     int chain_downgrades = 0;            // groups of four units whose chain flags failed sanitize_chain_plan (option "chain_downgrades"; 0 by construction)
     // cross-rank agreement (slab handles): everything that decides the sequence of passes / single steps / refreshes must be the same on every
     // slab of a tunnel — checked, not assumed (agree_rccl / agree_local)
@@ -384,6 +392,7 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->seams) (void)hipFree(h->seams);
     if (h->seam_plain) (void)hipFree(h->seam_plain);
     if (h->d_units) (void)hipFree(h->d_units);
+    for (auto &tp : h->trim_plans) if (tp.d_units) (void)hipFree(tp.d_units);
     if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->d_nbad) (void)hipFree(h->d_nbad);
     if (h->d_agree) (void)hipFree(h->d_agree);
@@ -479,12 +488,12 @@ static bool plan_by_time(const wt_handle *h)
     static const int timed = exp_env("WT_PLAN_TIMED") ? atoi(exp_env("WT_PLAN_TIMED")) : 1;
     return h->fuse_chunk <= 0 && timed;
 }
-static void cut_units(wt_handle *h, const float *colw, MarchPlan *out)
+static void cut_units(wt_handle *h, const float *colw, MarchPlan *out, const MarchRange *range = nullptr)
 {
     const Geom &g = h->g;
     const int depth = h->march_depth, win = 64 * h->march_s;
     const long target = h->plan_target;
-    const MarchRange r = depth >= 3 ? march_range3(g, depth) : march_range(g);
+    const MarchRange r = range ? *range : (depth >= 3 ? march_range3(g, depth) : march_range(g));
     // four steps per pass: class masks cover ib - ia + 6 columns, and the last unit of a window marches at least two
     // cost of a column that is not plain fluid, in plain columns: 1 + alpha; `over`: columns a unit iterates over beyond its own (pipeline
     // fill and drain of a `depth`-step pass); `tail`: the outlet column's extra stages — see build_march_plan_timed
@@ -516,6 +525,7 @@ static int upload_units(wt_handle *h, const MarchPlan &plan_in)
         const int max_solo = (h->march_depth == 4 ? MARCH3_MAX_CHUNK - 3 : (h->march_depth == 3 ? MARCH3_MAX_CHUNK : MARCH_MAX_CHUNK)) - 2;
         h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), h->g, h->march_depth, max_solo);
     }
+    for (auto &tp : h->trim_plans) tp.valid = false;       // cut from the kept plan's costs: stale now
     h->n_chain_units = 0;
     for (const MarchUnit &u : pl.units) h->n_chain_units += (u.flags & MU_CHAIN) != 0;
     const size_t total = pl.units.size();
@@ -605,6 +615,7 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
 
     h->plan_target = target;
     h->plan_tuned = false;
+    h->colw_kept.clear();
     MarchPlan pl;
     cut_units(h, nullptr, &pl);
     WT_TRY(upload_units(h, pl));
@@ -834,6 +845,10 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->tune = value != 0.0;
         return h->plan_tuned ? rebuild_fuse_plan(h) : WT_OK;
     }
+    if (strcmp(name, "trim_ghosts") == 0) {
+        h->trim = value != 0.0;
+        return WT_OK;
+    }
     if (strcmp(name, "fast_math") == 0) {
         if (value != 0.0 && h->dtype != WT_F32) return fail(WT_ERR_STATE, "fast_math is an fp32 option");
         h->fast_math = value != 0.0;
@@ -863,6 +878,8 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "tune_gain") == 0) { *value = h->plan_tuned ? h->tune_gain : 0.0; return WT_OK; }          // makespan modelled plan / kept plan
     if (strcmp(name, "single_steps") == 0) { *value = (double)h->single_steps; return WT_OK; }   // whole steps taken by k_step since the last init / write_f
     if (strcmp(name, "passes") == 0) { *value = (double)h->passes; return WT_OK; }
+    if (strcmp(name, "trim_ghosts") == 0) { *value = h->trim ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "trimmed_passes") == 0) { *value = (double)h->trimmed_passes; return WT_OK; }
     if (strcmp(name, "pass_depth") == 0) { *value = h->fuse_ready ? eff_depth(h) : 0; return WT_OK; }       // steps a full pass takes for the tau of the last stepping call
     if (strcmp(name, "chain_downgrades") == 0) { *value = h->chain_downgrades; return WT_OK; }
     if (strcmp(name, "agree_check") == 0) { *value = h->agree_check ? 1.0 : 0.0; return WT_OK; }
@@ -1246,6 +1263,44 @@ static int ensure_clocks(wt_handle *h)
     return WT_OK;
 }
 
+// The unit list of a pass that leaves `v_after` exact ghost columns (fewer than the kept plan's range covers): the kept plan's range shrunk to
+// the owned columns + v_after ghost columns at every LOCAL slab edge (the tunnel's own ends are marched as always).  Same planners, same
+// invariants, same tables; cut with the column costs the kept plan was cut with.  Every plan computes the same bits in the columns it marches.
+static int trim_plan_for(wt_handle *h, int v_after, const MarchUnit **units, int *nunits)
+{
+    wt_handle::TrimPlan *tp = nullptr;
+    for (auto &t : h->trim_plans) if (t.v_after == v_after) tp = &t;
+    if (!tp) { h->trim_plans.emplace_back(); tp = &h->trim_plans.back(); tp->v_after = v_after; }
+    if (!tp->valid) {
+        const Geom &g = h->g;
+        MarchRange r = march_range3(g, h->march_depth);
+        if (h->gl) r.i_begin = std::max(r.i_begin, h->gl - v_after);
+        if (h->gr) r.i_end = std::min(r.i_end, h->gl + h->width + v_after);
+        MarchPlan pl;
+        cut_units(h, h->colw_kept.empty() ? nullptr : h->colw_kept.data(), &pl, &r);
+        if (!h->host_wcls.empty()) {
+            const int max_solo = (h->march_depth == 4 ? MARCH3_MAX_CHUNK - 3 : MARCH3_MAX_CHUNK) - 2;
+            h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), g, h->march_depth, max_solo);
+        }
+        const size_t total = pl.units.size();
+        if (total > tp->cap) {
+            if (tp->d_units) { HIP_TRY(hipFree(tp->d_units)); tp->d_units = nullptr; tp->cap = 0; }
+            const size_t cap = total + total / 4 + 64;
+            HIP_TRY(hipMalloc((void **)&tp->d_units, cap * sizeof(MarchUnit)));
+            tp->cap = cap;
+        }
+        if (total > 0) {
+            HIP_TRY(hipMemcpyAsync(tp->d_units, pl.units.data(), total * sizeof(MarchUnit), hipMemcpyHostToDevice, h->s_compute));
+            HIP_TRY(hipStreamSynchronize(h->s_compute));
+        }
+        tp->n_units = (int)total;
+        tp->valid = true;
+    }
+    *units = tp->d_units;
+    *nunits = tp->n_units;
+    return WT_OK;
+}
+
 // Three steps in one pass (step_march3.hpp), or two on the same tables (depth = 2: what a step count leaves over).
 // A = f[cur] (time t), B = f[1-cur] (receives time t + depth).
 template <typename T, int S, int FD>
@@ -1284,6 +1339,16 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
         }
     }
     p.units = h->d_units; p.nunits = h->n_units;
+    if (h->nranks > 1 && h->trim && !h->clk_on) {
+        // ghost columns that will still be exact after this pass: the others are not marched (trim_plan_for)
+        const int v_full = h->halo - (h->march_depth - 1), v_after = std::max(0, std::min(h->ghost_valid - depth, v_full));
+        if (v_after < v_full) {
+            const MarchUnit *tu = nullptr;
+            int tn = 0;
+            WT_TRY(trim_plan_for(h, v_after, &tu, &tn));
+            if (tn > 0) { p.units = tu; p.nunits = tn; h->trimmed_passes += 1; }
+        }
+    }
     if (h->clk_on) HIP_TRY(hipEventRecord(h->ev_t0, st));       // tuning passes: the marching kernel alone is timed
     if (p.nunits > 0) {
         const dim3 grid((unsigned)((p.nunits + 3) / 4));
@@ -1371,6 +1436,7 @@ static int tune_fuse_plan(wt_handle *h, double tau, double u0)
     const Geom &g = h->g;
     const int ld = g.nxl + 2;
     std::vector<float> colw((size_t)h->n_win * ld, 1.0f);
+    std::vector<float> colw_cur, colw_best;          // the corrections the present / the best plan was cut with (empty: the modelled costs)
     std::vector<MarchUnit> best = h->host_units;
     double best_span = 0.0, first_span = 0.0;
     std::vector<unsigned long long> clk;
@@ -1434,7 +1500,7 @@ static int tune_fuse_plan(wt_handle *h, double tau, double u0)
         }
         if (span <= 0.0) break;
         if (it == 0) first_span = span;
-        if (!have_best || span < best_span) { best_span = span; best = h->host_units; have_best = true; uploaded_best = true; }
+        if (!have_best || span < best_span) { best_span = span; best = h->host_units; colw_best = colw_cur; have_best = true; uploaded_best = true; }
         else uploaded_best = false;
         h->tune_rounds = it + 1;
         if (it + 1 == rounds) break;
@@ -1461,8 +1527,10 @@ static int tune_fuse_plan(wt_handle *h, double tau, double u0)
         cut_units(h, colw.data(), &pl);
         if (pl.units.empty()) break;
         WT_TRY(upload_units(h, pl));
+        colw_cur = colw;
         uploaded_best = false;
     }
+    h->colw_kept = colw_best;                        // the trimmed plans of a slab (trim_plan_for) are cut with the kept plan's costs
     if (have_best && !uploaded_best) {
         MarchPlan pl;
         pl.units = best;

@@ -31,7 +31,7 @@ def slab_bounds(nx: int, nranks: int, edges: Optional[List[int]] = None) -> List
     return [(edges[r], edges[r + 1] - edges[r]) for r in range(nranks)]
 
 
-DEFAULT_HALO = 17       # ghost columns per interior side: one refresh step + four four-step passes between two exchanges
+DEFAULT_HALO = 29       # ghost columns per interior side: one refresh step + seven four-step passes between two exchanges (profiles/r04_g_trim_ab.txt)
 
 
 def default_halo(bounds: List[Tuple[int, int]], halo: Optional[int] = None) -> int:
@@ -332,7 +332,7 @@ class _LocalSlabEngine:
 
 class LocalSlabWindTunnel(WindTunnel):
     """:class:`WindTunnel` over several GPUs driven by ONE process (no torch.distributed, no RCCL):
-    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=17, nx=8192, ny=4096)``."""
+    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=29, nx=8192, ny=4096)``."""
 
     def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: Optional[int] = None, edges=None, **kwargs):
         self.devices = [int(d) for d in devices]

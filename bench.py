@@ -92,9 +92,11 @@ def parse_args():
     ap.add_argument("--u0", type=float, default=0.06)
     ap.add_argument("--tau", type=float, default=None)
     ap.add_argument("--re", type=float, default=None, help="Reynolds number: tau = 0.5 + 3 U0 (NX / 1.84) / Re (SURVEY 8b) in place of --tau")
-    ap.add_argument("--halo", type=int, default=17,
-                    help="ghost columns per interior slab side (exchange every `halo` steps; 17 = one single refresh step + four four-step passes: "
-                         "2 %% faster than 16 = 1 + 4 + 4 + 4 + 3 in a locally linked group, profiles/r03_g_group_vs_alone.txt)")
+    ap.add_argument("--halo", type=int, default=29,
+                    help="ghost columns per interior slab side (exchange every `halo` steps; 29 = one single refresh step + seven four-step passes.  With "
+                         "the ghost columns TRIMMED pass by pass (option trim_ghosts, round 4) a deeper halo costs little redundant work and halves the "
+                         "refresh steps: a locally linked 8-slab group runs 160 us per step at 17 untrimmed, 156 trimmed, 143 at 29, 139 at 41-49, "
+                         "profiles/r04_g_trim_ab.txt; the exchange grows with it, so not deeper than 29 by default)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the NumPy CPU baseline (0 = skip)")
     ap.add_argument("--fuse", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="two steps per pass over the lattice (csrc/step_march.hpp; fp32; bit-identical): -1 library "

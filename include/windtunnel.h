@@ -128,6 +128,10 @@ WT_API const char *wt_version(void);
  *       multiply-adds, v_rcp / v_rsq for the divisions and the square root (csrc/d2q9.hpp collide_contracted).  Held to BASELINE.md's
  *       tolerance against the oracle (|d rho| <= 1e-5, |d u| <= 5e-6; tests/test_gpu_fast_math.py), +19 % on 4096^2, +36 % on a
  *       544-column slab.  k_step (single steps, HBM-bound) keeps the reference arithmetic.
+ *   "trim_ghosts" (default 1, slab handles, three / four steps per pass): a pass that starts with gv exact ghost columns and advances k steps
+ *       leaves gv - k of them exact; the columns beyond are not marched at all (their results could never be read) — one unit list per
+ *       remaining depth, cut from the kept plan's column costs the first time it is needed.  Between two refreshes a slab with halo 17 marches
+ *       12, 8, 4 and 0 ghost columns per side instead of 14 four times.  "trimmed_passes" counts the passes that ran on a trimmed list.
  *   "agree_check" (default 1, slab handles): every slab of a tunnel must take the SAME sequence of fused passes, single steps and ghost
  *       refreshes — over RCCL each rank decides alone and the exchange is collective, so a rank that decides differently is a hang.  The
  *       library therefore compares, across the slabs, everything that decides that sequence (lattice, split, halo, dtype, the options above,

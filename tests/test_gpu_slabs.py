@@ -362,3 +362,35 @@ def test_pass_depth_reports_the_pass_actually_taken(pkg):
         assert e.get_option("passes") == 0                    # counted since the last init / write_f, like single_steps
         e.step(9, 0.58, 0.06)
         assert (e.get_option("fuse_depth"), e.get_option("pass_depth"), e.get_option("passes")) == (4, 3, 3)
+
+
+@pytest.mark.parametrize("dtype,halo", [("float32", 17), ("float32", 9), ("float64", 17)])
+def test_trimmed_ghost_marching_changes_no_bit(pkg, dtype, halo):
+    """trim_ghosts: between two refreshes a pass marches only the ghost columns that will still be exact after it (one unit list per remaining
+    depth, cut lazily).  Owned columns, (rho, ux, uy) and the reductions equal the single lattice and the untrimmed group bit for bit through
+    several refresh cycles, uneven step counts included."""
+    nx, ny, nranks = 2304, 1024, 3
+    mask = pkg.geometry.build_geometry(nx, ny, 7.0, None, "naca2412").mask
+    chunks = [3 * halo + 5, 7, 4 * halo, 9]
+    f0, m0, r0, F0 = _single(pkg, mask, chunks, 0.58, 0.06, dtype)
+    out = {}
+    for trim in (1, 0):
+        es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+        try:
+            pkg.Engine.link_local(es)
+            for e in es:
+                e.set_option("fuse_steps", 2)
+                e.set_option("trim_ghosts", trim)
+                e.set_mask(mask); e.init_equilibrium(0.06)
+            for n in chunks:
+                pkg.Engine.step_group(es, n, 0.58, 0.06)
+            out[trim] = (np.concatenate([e.read_f() for e in es], axis=2), [np.concatenate(p, axis=1) for p in zip(*[e.read_macro() for e in es])],
+                         [e.get_option("trimmed_passes") for e in es], [e.get_option("passes") for e in es])
+        finally:
+            for e in es:
+                e.close()
+    assert all(t > 0 for t in out[1][2]) and all(t == 0 for t in out[0][2]), (out[1][2], out[0][2])
+    assert out[1][3] == out[0][3]                                  # the same schedule either way
+    for trim in (1, 0):
+        assert bits_equal(f0, out[trim][0])
+        assert all(bits_equal(a, b) for a, b in zip(m0, out[trim][1]))
