@@ -185,6 +185,9 @@ struct wt_handle {
     std::vector<TrimPlan> trim_plans;
     std::vector<float> colw_kept;        // column-cost corrections of the plan tune_fuse_plan kept (empty: the modelled costs)
     bool trim = true;                    // option "trim_ghosts"
+    int refresh_mode = 0;                // option "refresh": 0 = a single step with the exchange beside its interior columns, 1 = the exchange at a
+                                         // pass boundary (not overlapped), every step of the cycle fused
+    long long boundary_exchanges = 0;    // exchanges taken at a pass boundary (option "boundary_exchanges")
     long long trimmed_passes = 0;        // passes that marched a trimmed range (option "trimmed_passes")
     int chain_downgrades = 0;            // groups of four units whose chain flags failed sanitize_chain_plan (option "chain_downgrades"; 0 by construction)
     // cross-rank agreement (slab handles): everything that decides the sequence of passes / single steps / refreshes must be the same on every
@@ -849,6 +852,11 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->trim = value != 0.0;
         return WT_OK;
     }
+    if (strcmp(name, "refresh") == 0) {
+        if (!(value == 0.0 || value == 1.0)) return fail(WT_ERR_ARG, "refresh must be 0 (overlapped single step) or 1 (exchange at a pass boundary)");
+        h->refresh_mode = (int)value;
+        return WT_OK;
+    }
     if (strcmp(name, "fast_math") == 0) {
         if (value != 0.0 && h->dtype != WT_F32) return fail(WT_ERR_STATE, "fast_math is an fp32 option");
         h->fast_math = value != 0.0;
@@ -879,6 +887,8 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "single_steps") == 0) { *value = (double)h->single_steps; return WT_OK; }   // whole steps taken by k_step since the last init / write_f
     if (strcmp(name, "passes") == 0) { *value = (double)h->passes; return WT_OK; }
     if (strcmp(name, "trim_ghosts") == 0) { *value = h->trim ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "refresh") == 0) { *value = h->refresh_mode; return WT_OK; }
+    if (strcmp(name, "boundary_exchanges") == 0) { *value = (double)h->boundary_exchanges; return WT_OK; }
     if (strcmp(name, "trimmed_passes") == 0) { *value = (double)h->trimmed_passes; return WT_OK; }
     if (strcmp(name, "pass_depth") == 0) { *value = h->fuse_ready ? eff_depth(h) : 0; return WT_OK; }       // steps a full pass takes for the tau of the last stepping call
     if (strcmp(name, "chain_downgrades") == 0) { *value = h->chain_downgrades; return WT_OK; }
@@ -1122,6 +1132,24 @@ static int halo_begin(wt_handle *h)
 }
 
 static inline bool needs_halo(const wt_handle *h) { return h->nranks > 1 && h->ghost_valid <= 0; }
+
+// refresh = 1: is an exchange due before the next step of `left` steps to go?  (A fused pass needs two exact ghost columns, a last single step one.)
+static inline bool boundary_exchange_due(const wt_handle *h, int left)
+{
+    return h->nranks > 1 && h->refresh_mode == 1 && h->fuse_ready && left > 0 && h->ghost_valid < std::min(left, 2);
+}
+// ... and the exchange itself: all `halo` ghost columns of lattice `cur` from the neighbours, the compute stream waits for them.  Not overlapped
+// with anything; in exchange no step of the cycle is a single k_step (which runs at the un-fused rate).
+static int exchange_at_boundary(wt_handle *h)
+{
+    WT_TRY(halo_begin(h));
+    if (h->xt_on) { HIP_TRY(hipEventRecord(xt_event(h, 2), h->s_compute)); HIP_TRY(hipEventRecord(xt_event(h, 3), h->s_compute)); }      // (no interior kernel beside it)
+    HIP_TRY(hipStreamWaitEvent(h->s_compute, h->ev_halo, 0));
+    if (h->xt_on) { HIP_TRY(hipEventRecord(xt_event(h, 4), h->s_compute)); h->xt_n += 1; }
+    h->ghost_valid = h->halo;
+    h->boundary_exchanges += 1;
+    return WT_OK;
+}
 
 // One step of one handle.  `refreshed`: halo_begin was enqueued for this step; the refresh is
 // overlapped with the interior columns:  [ghost refresh on s_comm] || [interior on s_compute]
@@ -1579,6 +1607,7 @@ static int schedule_fingerprint(const wt_handle *h, SchedField *f)
     put("option fast_div (WT_FAST_DIV)", h->fast_div ? 1 : 0);
     put("option fast_math", h->fast_math ? 1 : 0);
     put("option plan_columns", h->plan_columns);
+    put("option refresh", h->refresh_mode);
     put("resident wave slots of the device (CUs x 4 SIMDs x waves)", wave_slots_of(h));
     put("marching kernels eligible (widest slab below 4 GiB, even NY)", fuse_eligible(h) ? 1 : 0);
     put("mask set", h->mask_set ? 1 : 0);
@@ -1675,6 +1704,10 @@ static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
     WT_TRY(prepare_steps(h, nsteps, tau, u0));
     int s = 0;
     while (s < nsteps) {
+        if (boundary_exchange_due(h, nsteps - s)) {
+            if (h->transport == TR_NONE) return fail(WT_ERR_STATE, "slab handle has no transport (wt_comm_init_rank / wt_link_local)");
+            WT_TRY(exchange_at_boundary(h));
+        }
         const int k = fuse_stride(h, nsteps - s);
         if (k > 0) {
             WT_TRY(step_fused(h, tau, u0, s + k == nsteps, k));
@@ -1700,6 +1733,11 @@ extern "C" int wt_plan_steps(wt_handle *h, int nsteps, double tau, int *seq, int
     const int gv0 = h->ghost_valid;
     int n = 0, s = 0;
     while (s < nsteps) {
+        if (boundary_exchange_due(h, nsteps - s)) {          // refresh = 1: -2 = an exchange at a pass boundary (no step)
+            if (n < cap) seq[n] = -2;
+            n++;
+            h->ghost_valid = h->halo;
+        }
         const int k = fuse_stride(h, nsteps - s);
         int code;
         if (k > 0) {
@@ -1872,6 +1910,29 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
     WT_TRY(group_prepare(hs, n, nsteps, tau, u0));
     int s = 0;
     while (s < nsteps) {
+        // refresh = 1 (agreed by the group): an exchange at a pass boundary as soon as any slab is short of exact ghost columns
+        bool xdue = false;
+        for (int r = 0; r < n && n > 1; r++) xdue = xdue || boundary_exchange_due(hs[r], nsteps - s);
+        if (xdue) {
+            for (int r = 0; r < n; r++) {                      // every slab's comm stream must see its neighbours' finished lattices
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                HIP_TRY(hipEventRecord(hs[r]->ev_state, hs[r]->s_compute));
+            }
+            for (int r = 0; r < n; r++) {
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_comm, hs[r]->peer_l->ev_state, 0));
+                if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_comm, hs[r]->peer_r->ev_state, 0));
+            }
+            for (int r = 0; r < n; r++) {
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                WT_TRY(exchange_at_boundary(hs[r]));
+            }
+            for (int r = 0; r < n; r++) {                      // a peer's pass after next overwrites the lattice my copies read: it waits for them
+                HIP_TRY(hipSetDevice(hs[r]->device));
+                if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_l->ev_halo, 0));
+                if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_r->ev_halo, 0));
+            }
+        }
         // one pass length for the whole group: the shortest plan depth and the fewest exact ghost columns of any slab (edge
         // slabs are narrower than interior ones and may have chosen another depth; a depth-4 table also runs 2- and 3-step passes)
         int depth = 1 << 30, avail = nsteps - s;

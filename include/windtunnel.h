@@ -132,6 +132,11 @@ WT_API const char *wt_version(void);
  *       leaves gv - k of them exact; the columns beyond are not marched at all (their results could never be read) — one unit list per
  *       remaining depth, cut from the kept plan's column costs the first time it is needed.  Between two refreshes a slab with halo 17 marches
  *       12, 8, 4 and 0 ghost columns per side instead of 14 four times.  "trimmed_passes" counts the passes that ran on a trimmed list.
+ *   "refresh" (default 0, slab handles): how the ghost columns are renewed.  0: by a SINGLE step (k_step) whose interior columns run beside the
+ *       exchange, the two edge strips after it — the exchange hides, the step runs at the un-fused rate and the pass after it builds its halo
+ *       tables by the gather path.  1: by an exchange at a PASS BOUNDARY — nothing runs beside it, and every step of the cycle is a fused one
+ *       ("single_steps" stays 0, "boundary_exchanges" counts them; wt_plan_steps reports such an exchange as -2).  Which is faster depends on
+ *       what an exchange costs on the links (profiles/r04_h_refresh_modes.txt); all slabs of a tunnel must choose alike (checked).
  *   "agree_check" (default 1, slab handles): every slab of a tunnel must take the SAME sequence of fused passes, single steps and ghost
  *       refreshes — over RCCL each rank decides alone and the exchange is collective, so a rank that decides differently is a hang.  The
  *       library therefore compares, across the slabs, everything that decides that sequence (lattice, split, halo, dtype, the options above,

@@ -394,3 +394,50 @@ def test_trimmed_ghost_marching_changes_no_bit(pkg, dtype, halo):
     for trim in (1, 0):
         assert bits_equal(f0, out[trim][0])
         assert all(bits_equal(a, b) for a, b in zip(m0, out[trim][1]))
+
+
+@pytest.mark.parametrize("dtype,nranks,halo", [("float32", 4, 17), ("float32", 2, 29), ("float64", 3, 13)])
+def test_all_fused_refresh_cycle_equals_single_lattice(pkg, dtype, nranks, halo):
+    """option refresh = 1: the ghost columns are renewed by an exchange at a pass boundary and EVERY step of a cycle is a
+    fused one — single_steps stays 0 through more than three refresh cycles, the planned schedule (-2 = exchange) is the one that runs, and
+    owned columns and (rho, ux, uy) equal the single lattice bit for bit."""
+    nx, ny = 600 * nranks, 1024
+    mask = pkg.geometry.build_geometry(nx, ny, 7.0, None, "naca2412").mask
+    chunks = [2 * halo, halo + 8, 40, 4 * halo]
+    f0, m0, _, _ = _single(pkg, mask, chunks, 0.58, 0.06, dtype)
+    es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_option("refresh", 1)
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        assert all(e.get_option("fuse_active") == 1.0 for e in es)
+        for n in chunks:
+            plan = es[0].plan_steps(n, 0.58)
+            assert all(e.plan_steps(n, 0.58) == plan for e in es)
+            assert all(k >= 2 or k == -2 for k in plan) and sum(k for k in plan if k > 0) == n       # fused passes and boundary exchanges only
+            x0 = [e.get_option("boundary_exchanges") for e in es]
+            pkg.Engine.step_group(es, n, 0.58, 0.06)
+            assert [e.get_option("boundary_exchanges") - a for e, a in zip(es, x0)] == [plan.count(-2)] * nranks
+        assert all(e.get_option("single_steps") == 0 for e in es)
+        assert all(e.get_option("boundary_exchanges") >= 4 for e in es)
+        f1 = np.concatenate([e.read_f() for e in es], axis=2)
+        m1 = [np.concatenate(p, axis=1) for p in zip(*[e.read_macro() for e in es])]
+    finally:
+        for e in es:
+            e.close()
+    assert bits_equal(f0, f1)
+    assert all(bits_equal(a, b) for a, b in zip(m0, m1))
+    # a group whose slabs chose different refresh modes is refused (the modes exchange at different steps)
+    es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    try:
+        pkg.Engine.link_local(es)
+        for r, e in enumerate(es):
+            e.set_option("refresh", 1 if r == 0 else 0)
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        with pytest.raises(pkg.WTError) as ei:
+            pkg.Engine.step_group(es, 20, 0.58, 0.06)
+        assert "disagree" in str(ei.value) and "refresh" in str(ei.value)
+    finally:
+        for e in es:
+            e.close()

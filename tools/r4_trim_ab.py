@@ -9,12 +9,13 @@ P = 8
 mask = pkg.geometry.build_geometry(nx, ny, 10.0, None, "naca6409").mask
 for halo in [int(a) for a in sys.argv[1:]] or [17, 25, 33]:
     for rep in range(2):
-        for trim in (0, 1):
+        for trim, refresh in ((0, 0), (1, 0), (1, 1)) if os.environ.get("WT_REFRESH_AB") else ((0, 0), (1, 0)):
             es = [pkg.Engine(nx, ny, rank=r, nranks=P, halo=halo) for r in range(P)]
             try:
                 pkg.Engine.link_local(es)
                 for e in es:
                     e.set_option("trim_ghosts", trim)
+                    e.set_option("refresh", refresh)
                     e.set_mask(mask); e.init_equilibrium(0.06)
                 pkg.Engine.step_group(es, 10 * halo, 0.58, 0.06)
                 for e in es:
@@ -25,7 +26,7 @@ for halo in [int(a) for a in sys.argv[1:]] or [17, 25, 33]:
                 for e in es:
                     e.sync()
                 us = (time.perf_counter() - t0) / n * 1e6
-                print(f"halo {halo:2d} trim {trim}: {us:7.2f} us per step of the group ({nx * ny / us / 1e3:.0f} GLUPS on one GPU), trimmed passes {int(es[1].get_option('trimmed_passes'))} of {int(es[1].get_option('passes'))}", flush=True)
+                print(f"halo {halo:2d} trim {trim} refresh {refresh}: {us:7.2f} us per step of the group ({nx * ny / us / 1e3:.0f} GLUPS on one GPU), trimmed passes {int(es[1].get_option('trimmed_passes'))} of {int(es[1].get_option('passes'))}, single steps {int(es[1].get_option('single_steps'))}, boundary exchanges {int(es[1].get_option('boundary_exchanges'))}", flush=True)
             finally:
                 for e in es:
                     e.close()
