@@ -73,13 +73,16 @@ def balanced_edges(edges: List[int], cost: List[float], min_width: int) -> List[
 
 
 def measure_slab_cost(mask: np.ndarray, edges: List[int], rank: int, halo: int, dtype="float32", device: int = 0, tau: float = 0.58,
-                      u0: float = 0.06, steps: int = 200, options=None) -> float:
+                      u0: float = 0.06, steps: int = 200, options=None, trimmed: bool = True) -> float:
     """Microseconds per step of slab `rank` of the split on its own: a stand-alone handle of the slab's owned + ghost columns on the mask
     columns it would hold (its cut edges act as inlet / outlet, which costs a little more than the ghost columns of the real slab).
-    No neighbour and no communicator is involved, so the ranks of a process group measure their candidate slabs side by side."""
+    No neighbour and no communicator is involved, so the ranks of a process group measure their candidate slabs side by side.
+    trimmed: the real slab marches, pass by pass, only the ghost columns that stay exact (library option trim_ghosts) — on average half of
+    them — so the stand-in carries (halo + 1) // 2 ghost columns per interior side instead of all `halo`."""
     from ._capi import Engine
     nx = mask.shape[1]
-    lo, hi = max(0, edges[rank] - halo), min(nx, edges[rank + 1] + halo)
+    ghosts = (halo + 1) // 2 if trimmed else halo
+    lo, hi = max(0, edges[rank] - ghosts), min(nx, edges[rank + 1] + ghosts)
     with Engine(hi - lo, mask.shape[0], dtype=dtype, device=device) as e:
         for k, v in (options or {}).items():
             e.set_option(k, v)
