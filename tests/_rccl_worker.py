@@ -16,8 +16,14 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    same = os.environ.get("WT_RCCL_SAME_DEVICE") is not None      # experiment: every rank on ONE GPU (torch's group over gloo; only the library talks RCCL)
+    if same:
+        local = int(os.environ["WT_RCCL_SAME_DEVICE"])
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if same:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import airfoil_cfd_tool_amd as pkg
     nx, ny, halo = 2048, 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 16
     chunks = [1, 2, 3, 40, 17]
@@ -78,7 +84,7 @@ def main():
     if rank == 0:
         print(f"rccl slabs: a rank with another fuse_depth is refused on every rank: {'PASS' if all(got) else 'FAIL'}", flush=True)
     ok &= all(got)
-    flag = torch.tensor([1 if ok else 0], device=torch.device("cuda", local))
+    flag = torch.tensor([1 if ok else 0], device=torch.device("cpu") if same else torch.device("cuda", local))
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.barrier()
     dist.destroy_process_group()
