@@ -51,11 +51,25 @@ __device__ __forceinline__ void chain_publish(V (&slot)[3][64], int &flag, int l
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     *(volatile int *)&flag = 1;
 }
+// The poll is BOUNDED: on a well-formed plan the partner publishes within a stage or two — the library checks every plan
+// it uploads (sanitize_chain_plan) — but a wave must never be able to spin for ever on a GPU other people share.  After CHAIN_POLL_LIMIT polls
+// (seconds; a healthy hand-over takes microseconds) the unit raises the host-visible word `stuck`, goes on with whatever the slot holds and
+// terminates normally; the host turns the word into WT_ERR_STATE at its next synchronisation (windtunnel.hip check_stuck).
+static constexpr int CHAIN_POLL_LIMIT = 1 << 24;
 template <typename V>
-__device__ __forceinline__ void chain_receive(const V (&slot)[3][64], const int &flag, int lane, V (&r)[3])
+__device__ __forceinline__ void chain_receive(const V (&slot)[3][64], const int &flag, int lane, V (&r)[3], unsigned int *stuck)
 {
 #ifndef WT_CHAIN_NOBARRIER   // (timing experiment: no synchronisation at all — wrong results)
-    while (__builtin_amdgcn_readfirstlane(*(const volatile int *)&flag) == 0) __builtin_amdgcn_s_sleep(1);
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(*(const volatile int *)&flag) == 0, 0)) {
+        int polls = 0;
+        while (__builtin_amdgcn_readfirstlane(*(const volatile int *)&flag) == 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > CHAIN_POLL_LIMIT) {
+                if (lane == 0 && stuck) atomicOr(stuck, 1u);
+                break;
+            }
+        }
+    }
 #endif
     asm volatile("" ::: "memory");
     r[0] = slot[0][lane];
@@ -155,8 +169,8 @@ struct ChainUnit {
             if (!((MASK >> (k - 1)) & 1)) continue;
             V3 ma[3];
             if ((MASK >> (k - 2)) & 1) { ma[0] = G[k - 1][P::A0]; ma[1] = G[k - 1][P::A1]; ma[2] = G[k - 1][P::A2]; }
-            else chain_receive(lds.x[1][k - 2][pos ^ 3], lds.flag[1][k - 2][pos ^ 3], lane, ma);           // RE == k - 1 (positions 1 <-> 2)
-            if (RS == k - 1) chain_receive(lds.x[0][k - 2][pos ^ 1], lds.flag[0][k - 2][pos ^ 1], lane, sm[k - 2]);
+            else chain_receive(lds.x[1][k - 2][pos ^ 3], lds.flag[1][k - 2][pos ^ 3], lane, ma, p.stuck);           // RE == k - 1 (positions 1 <-> 2)
+            if (RS == k - 1) chain_receive(lds.x[0][k - 2][pos ^ 1], lds.flag[0][k - 2][pos ^ 1], lane, sm[k - 2], p.stuck);
             if (k == DEPTH) chain_stage<DIR, EMIT, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 2], G[k], mac);
             else chain_stage<DIR, false, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 2], G[k], mac);
             if (k < DEPTH && PS == k) chain_publish(lds.x[0][k - 1][pos], lds.flag[0][k - 1][pos], lane, G[k][P::A0], G[k][P::A1], G[k][P::A2]);

@@ -296,6 +296,7 @@ struct MarchParams {
     T U0;
     int rev;
     unsigned long long *clk = nullptr;   // tuning passes only (tune_fuse_plan): [unit] = {start, end} of every unit in s_memtime ticks
+    unsigned int *stuck = nullptr;       // host-visible word: a chain unit that gave up waiting for its partner's hand-over sets it (step_chain.hpp)
 };
 
 // S consecutive rows of one column and direction, held by one lane

@@ -189,6 +189,8 @@ struct wt_handle {
                                          // pass boundary (not overlapped), every step of the cycle fused
     long long boundary_exchanges = 0;    // exchanges taken at a pass boundary (option "boundary_exchanges")
     long long trimmed_passes = 0;        // passes that marched a trimmed range (option "trimmed_passes")
+    unsigned int *stuck_host = nullptr;  // host-mapped word a chain unit raises when it gives up waiting for a hand-over (step_chain.hpp chain_receive)
+    unsigned int *stuck_dev = nullptr;
     int chain_downgrades = 0;            // groups of four units whose chain flags failed sanitize_chain_plan (option "chain_downgrades"; 0 by construction)
     // cross-rank agreement (slab handles): everything that decides the sequence of passes / single steps / refreshes must be the same on every
     // slab of a tunnel — checked, not assumed (agree_rccl / agree_local)
@@ -318,6 +320,9 @@ static int create_impl(int nx_g, int ny, int dtype, int device, int rank, int nr
     CREATE_TRY(hipMalloc((void **)&h->tiles, tile_bytes));
     CREATE_TRY(hipMalloc(&h->partials, kReduceBlocks * sizeof(ForcePartial)));
     CREATE_TRY(hipHostMalloc(&h->partials_host, kReduceBlocks * sizeof(ForcePartial)));
+    CREATE_TRY(hipHostMalloc((void **)&h->stuck_host, sizeof(unsigned int), hipHostMallocMapped));
+    *h->stuck_host = 0;
+    CREATE_TRY(hipHostGetDevicePointer((void **)&h->stuck_dev, h->stuck_host, 0));
     h->device_bytes = (long long)(2 * lat_bytes + macro_bytes + mask_bytes + tile_bytes + kReduceBlocks * sizeof(ForcePartial));
     int lo = 0, hi = 0;
     CREATE_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -399,6 +404,7 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->d_nbad) (void)hipFree(h->d_nbad);
     if (h->d_agree) (void)hipFree(h->d_agree);
+    if (h->stuck_host) (void)hipHostFree(h->stuck_host);
     if (h->cv_layer) (void)hipFree(h->cv_layer);
     if (h->cv_text) (void)hipFree(h->cv_text);
     if (h->cv_out) (void)hipFree(h->cv_out);
@@ -432,13 +438,23 @@ extern "C" int wt_get_info(const wt_handle *h, wt_info *info)
 extern "C" const char *wt_last_error(void) { return g_err; }
 extern "C" const char *wt_version(void) { return "libwindtunnel 0.1 (gfx950, D2Q9 pull, column-major SoA)"; }
 
+// A chain unit that gave up waiting for its partner's hand-over (step_chain.hpp: the poll is bounded) has raised the host-mapped word: the
+// state it produced is not to be trusted.  Looked at wherever the host has just synchronised with the device.
+static int check_stuck(wt_handle *h)
+{
+    if (h->stuck_host && *h->stuck_host != 0)
+        return fail(WT_ERR_STATE, "a chain unit of a marching pass gave up waiting for its partner's hand-over (an ill-formed unit plan reached the device): "
+                                  "the lattice state is not valid; re-initialise the handle");
+    return WT_OK;
+}
+
 extern "C" int wt_sync(wt_handle *h)
 {
     WT_TRY(check_handle(h));
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_comm));
-    return WT_OK;
+    return check_stuck(h);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -527,6 +543,13 @@ static int upload_units(wt_handle *h, const MarchPlan &plan_in)
     if (!h->host_wcls.empty()) {
         const int max_solo = (h->march_depth == 4 ? MARCH3_MAX_CHUNK - 3 : (h->march_depth == 3 ? MARCH3_MAX_CHUNK : MARCH_MAX_CHUNK)) - 2;
         h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), h->g, h->march_depth, max_solo);
+    }
+    if (const char *e = exp_env("WT_DEBUG_CORRUPT_PLAN")) {
+        // experiment builds only (tools/r4_stuck_check.py): strip the chain flags of ONE unit of the first chain block BEHIND the guard above, so that
+        // its start-seam partner waits for a hand-over that never comes — the bounded poll of chain_receive must end the unit and raise `stuck`
+        if (atoi(e) != 0)
+            for (size_t b = 0; b + 3 < pl.units.size(); b += 4)
+                if (pl.units[b].flags & MU_CHAIN) { pl.units[b + 1].flags = 0; break; }
     }
     for (auto &tp : h->trim_plans) tp.valid = false;       // cut from the kept plan's costs: stale now
     h->n_chain_units = 0;
@@ -987,6 +1010,7 @@ extern "C" int wt_init_equilibrium(wt_handle *h, double u0)
     WT_TRY(h->dtype == WT_F32 ? init_impl<float>(h, u0) : init_impl<double>(h, u0));
     h->cur = 0;
     h->inited = true;
+    if (h->stuck_host) { HIP_TRY(hipStreamSynchronize(h->s_compute)); *h->stuck_host = 0; }
     h->macro_stale = false;
     h->seams_valid = false;
     h->steps_done = 0;
@@ -1349,6 +1373,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)(h->passes & 1);
+    p.stuck = h->stuck_dev;
     if (h->clk_on) p.clk = h->d_clk + h->clk_off;
 #ifdef WT_UNIT_CLOCKS         // diagnostic build (tools/unit_clocks.py): every pass records its units
     else { WT_TRY(ensure_clocks(h)); p.clk = h->d_clk; }
@@ -2029,7 +2054,7 @@ static int read_plane(wt_handle *h, const T *src_cols, T *host_dst)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host_dst, h->stage, bytes, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    return WT_OK;
+    return check_stuck(h);
 }
 
 template <typename T>
