@@ -34,3 +34,14 @@ path = wt.save_png(os.path.join("/tmp", wt.png_name()))
 assert img.shape == (512, 1024, 4) and s.cl is not None and os.path.getsize(path) > 1000
 print("doc examples ok:", s, path)
 wt.close()
+
+# --- section 1, the canvas paragraph: trail layer + tracers + composited frame on the device ---
+from airfoil_cfd_tool_amd.tracers import Tracers
+with wtamd.WindTunnel(coords_after, "NACA 2412", nx=320, ny=160) as wt:
+    layer, tr = wt.trail_layer(), Tracers(wt, seed=1)
+    for _ in range(10):
+        wt.frame(render=False)
+        tr.draw(layer, 16.0)
+    img = wt.compose_frame(trails=layer)
+    assert img.shape == (360, 680, 4) and img.dtype == np.uint8
+print("canvas example ok")
