@@ -515,9 +515,11 @@ def main():
         except Exception as e:      # noqa: BLE001 - every failure is reported the same way
             die(rank, local_rank, "wt_comm_selftest (one-rank RCCL send/recv on this GPU)", e)
         try:
-            with_watchdog(COMM_TIMEOUT_S, rank, local_rank, "torch.distributed.init_process_group(nccl)",
-                          lambda: dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
-                                                          timeout=datetime.timedelta(seconds=COMM_TIMEOUT_S)))
+            # (plumbing tests on a 1-GPU box put every rank on one device, where torch's own NCCL group cannot exist: WT_BENCH_TORCH_BACKEND=gloo)
+            tb = os.environ.get("WT_BENCH_TORCH_BACKEND", "nccl")
+            with_watchdog(COMM_TIMEOUT_S, rank, local_rank, f"torch.distributed.init_process_group({tb})",
+                          lambda: dist.init_process_group(backend=tb, timeout=datetime.timedelta(seconds=COMM_TIMEOUT_S),
+                                                          **({"device_id": torch.device("cuda", local_rank)} if tb == "nccl" else {})))
         except Exception as e:      # noqa: BLE001
             die(rank, local_rank, "torch.distributed.init_process_group(nccl)", e)
 
@@ -660,9 +662,10 @@ def main():
                     "chain_downgrades": int(eng.get_option("chain_downgrades"))}
         rank_report = [None] * world
         dist.all_gather_object(rank_report, mine_rep)
-        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        tdev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        mine = torch.tensor([dev_ms], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([dev_ms], dtype=torch.float64, device=tdev)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         per_rank_ms = [float(g[0]) for g in gathered]

@@ -1,0 +1,58 @@
+"""GPU, ONE device: the library's multi-rank code as real processes, with a stand-in for RCCL underneath (tests/_rccl_stub/rccl_stub.cpp,
+LD_PRELOADed in front of the PRODUCTION libwindtunnel.so).  RCCL itself refuses two ranks on one GPU ("Duplicate GPU detected"), and no box with
+two GPUs has been available to any round — so until one is, this is where the code that only runs with nranks > 1 over TR_RCCL is executed at
+all: wt_comm_init_rank with its schedule-agreement all-reduce (and the refusal of a deviating rank on every rank), the grouped ghost-column
+exchange driven by every rank's own schedule, equal and caller-cut slabs, fp32 / fp64, two- and four-step plans, the worker's plan-agreement
+check, and bench.py --gpus N end to end with its per-rank report.  The stand-in keeps NCCL's matching rules (in-order per pair, grouped calls
+deadlock-free) and turns a size mismatch or a missing peer into an error instead of a hang; it says nothing about RCCL or xGMI themselves."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def stub(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("rccl_stub") / "librccl_stub.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "_rccl_stub", "rccl_stub.cpp"), "-ldl", "-lrt", "-lpthread"],
+                   check=True, capture_output=True, timeout=300)
+    return so
+
+
+def _env(stub, **extra):
+    env = dict(os.environ, LD_PRELOAD=stub, HSA_ENABLE_IPC_MODE_LEGACY="0", WT_RCCL_SAME_DEVICE="0")
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("world,halo", [(2, 16), (3, 5), (4, 29)])
+def test_slab_ranks_over_the_stand_in_transport_equal_single_lattice(stub, world, halo):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + world + halo), os.path.join(HERE, "_rccl_worker.py"), str(halo)]
+    r = subprocess.run(cmd, env=_env(stub), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert r.stdout.count("PASS") == 5 and "FAIL" not in r.stdout, r.stdout[-4000:]
+
+
+def test_bench_two_ranks_end_to_end_over_the_stand_in_transport(stub):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank): slabs cut by measured cost, the library's
+    communicator, warm-up, timed steps, the JSON line with the first-contact report of every rank."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29741",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "2048", "--ny", "1024", "--steps", "87", "--warmup", "29", "--cpu-steps", "0", "--balance", "1"]
+    r = subprocess.run(cmd, env=_env(stub, WT_BENCH_FORCE_DEVICE="0", WT_BENCH_TORCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and len(d["device_ms"]) == 2
+    assert d["comm_ranks_seen"] == [2] and [x["rank"] for x in d["ranks"]] == [0, 1]
+    assert sum(d["config"]["slab_widths"]) == 2048 and d["config"]["halo"] == 29 and len(d["config"]["balance"]) >= 1
+    for x in d["ranks"]:
+        assert x["comm_ranks"] == 2 and x["exchanges"] >= 3 and x["exchange_ms_each"] > 0 and x["agree_checks"] >= 2
+        assert x["fuse_active"] == 1 and x["passes"] > 0 and x["chain_downgrades"] == 0
+    assert len({(x["fuse_depth"], x["pass_depth"]) for x in d["ranks"]}) == 1
