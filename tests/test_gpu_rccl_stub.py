@@ -56,3 +56,13 @@ def test_bench_two_ranks_end_to_end_over_the_stand_in_transport(stub):
         assert x["comm_ranks"] == 2 and x["exchanges"] >= 3 and x["exchange_ms_each"] > 0 and x["agree_checks"] >= 2
         assert x["fuse_active"] == 1 and x["passes"] > 0 and x["chain_downgrades"] == 0
     assert len({(x["fuse_depth"], x["pass_depth"]) for x in d["ranks"]}) == 1
+
+
+@pytest.mark.parametrize("world,dtype", [(3, "float32"), (2, "float64")])
+def test_slab_wind_tunnel_host_class_over_the_stand_in_transport(stub, world, dtype):
+    """distributed.SlabWindTunnel on real slab engines: frame loop, AoA slider, combined reductions, gathered read-backs, and the vorticity field
+    whose ghost columns move over the transport (refresh_macro_ghosts, TR_RCCL branch: never run before) — against one WindTunnel."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29780 + world), os.path.join(HERE, "_slab_tunnel_worker.py"), dtype]
+    r = subprocess.run(cmd, env=_env(stub), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "PASS" in r.stdout and "FAIL" not in r.stdout, r.stdout[-4000:]
