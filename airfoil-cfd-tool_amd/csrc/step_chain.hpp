@@ -85,15 +85,15 @@ template <> struct ChainPops<-1> { static constexpr int B0 = 3, B1 = 6, B2 = 7, 
 
 // one more application of STEP_FS in registers (plain interior fluid): level k+1 of column c from level k of the column behind
 // (`mb`: its three populations moving forward), of column c itself (`Gc`) and of the column ahead (`ma`: three populations moving
-// backward); `hv` = column c's halo-table word (lanes 0..5, as in march_stage)
+// backward); `hv`, `lb` = column c's halo line and the level's first lane (as in march_stage)
 template <int DIR, bool WANT_MACRO, int FD, typename T, int S>
 __device__ __forceinline__ void chain_stage(const MarchParams<T> &p, int j0, int lane, bool far_win, const T (&feq0)[9], const MV<T, S> (&mb)[3],
-                                            const MV<T, S> (&Gc)[9], const MV<T, S> (&ma)[3], T hv, MV<T, S> (&out)[9], MV<T, S> (&mac)[3])
+                                            const MV<T, S> (&Gc)[9], const MV<T, S> (&ma)[3], T hv, int lb, MV<T, S> (&out)[9], MV<T, S> (&mac)[3])
 {
     typedef MV<T, S> V3;
     typedef ChainPops<DIR> P;
-    const T hb2 = readlane_t(hv, 0), hb5 = readlane_t(hv, 1), hb6 = readlane_t(hv, 2), ha4 = readlane_t(hv, 3), ha7 = readlane_t(hv, 4),
-            ha8 = readlane_t(hv, 5);
+    const T hb2 = readlane_t(hv, lb), hb5 = readlane_t(hv, lb + 1), hb6 = readlane_t(hv, lb + 2), ha4 = readlane_t(hv, lb + 16), ha7 = readlane_t(hv, lb + 17),
+            ha8 = readlane_t(hv, lb + 18);
     // halo value of population k's row outside the window (5, 6 from below; 7, 8 from above)
     auto edge = [&](int k) { return k == 5 ? hb5 : (k == 6 ? hb6 : (k == 7 ? ha7 : ha8)); };
     V3 fin[9];
@@ -114,12 +114,12 @@ template <int DIR, int DEPTH, bool EMIT, int FD, typename T, int S>
 struct ChainUnit {
     typedef MV<T, S> V3;
     typedef ChainPops<DIR> P;
-    static constexpr unsigned HREC = 8 * sizeof(T);
+    static constexpr unsigned HREC = M3_HL * sizeof(T);
     static constexpr int FULL = (1 << DEPTH) - 1;
 
     const MarchParams<T> &p;
     March3Addr<T, S> &m;
-    const __amdgpu_buffer_rsrc_t (&rh)[3];
+    const __amdgpu_buffer_rsrc_t &rh;
     const T (&feq0)[9];
     ChainLds<T, S, DEPTH> &lds;
     unsigned hoff;
@@ -131,9 +131,9 @@ struct ChainUnit {
     V3 in[9];                    // streamed inputs of the next level-1 column
     V3 sm[DEPTH - 1][3];         // level k (index k-1): forward-moving populations of the column two behind the front of that level
     V3 sc[DEPTH - 1][9];         //                      all nine of the column one behind it
-    T hv[DEPTH - 1];             // halo-table words of the columns the NEXT iteration's stages 2 .. DEPTH produce
+    T hv[DEPTH];                 // halo lines of the columns this iteration's stages 1 .. DEPTH work on: hv[j] = column x - j DIR
 
-    __device__ __forceinline__ ChainUnit(const MarchParams<T> &p_, March3Addr<T, S> &m_, const __amdgpu_buffer_rsrc_t (&rh_)[3], const T (&feq0_)[9],
+    __device__ __forceinline__ ChainUnit(const MarchParams<T> &p_, March3Addr<T, S> &m_, const __amdgpu_buffer_rsrc_t &rh_, const T (&feq0_)[9],
                                          ChainLds<T, S, DEPTH> &lds_)
         : p(p_), m(m_), rh(rh_), feq0(feq0_), lds(lds_) {}
 
@@ -152,14 +152,20 @@ struct ChainUnit {
         const MarchAddr<T, S> &a = m.a;
         constexpr bool S1 = (MASK & 1) != 0, LAST = (MASK >> (DEPTH - 1)) != 0;
         V3 nxt[9];
-        if (S1) march_load_stream(a, clampx(x + DIR), nxt);
-        T hvn[DEPTH - 1];
-#pragma unroll
-        for (int k = 1; k < DEPTH; k++) hvn[k - 1] = halo_load<T>(rh[k - 1], hoff, hcol(x + DIR - k * DIR));
+#ifdef WT_SPREAD_LOADS
+        constexpr bool SPREAD = S1 && DEPTH >= 3 && MASK == FULL;
+#else
+        constexpr bool SPREAD = false;
+#endif
+        const int cn = clampx(x + DIR);
+        if (S1 && !SPREAD) march_load_aligned(a, cn, nxt);
+        if (SPREAD) march_load_aligned_part<0>(a, cn, nxt);
+        const T hvn = halo_load<T>(rh, hoff, hcol(x + DIR));    // column x + DIR's halo line: the next iteration's stage 1, then handed on
         Seam3 sp;
         if (LAST) sp = seam3_fetch(m);
         V3 G[DEPTH + 1][9], mac[3];          // G[k] = level k computed in this iteration (G[DEPTH] = what is stored)
         if (S1) {
+            march_align_in(in, lane, hv[0]);
             march_step1<false, FD, T, S>(p, a, x, j0, far_win, false, false, feq0, in, G[1]);
             if (PS == 1) chain_publish(lds.x[0][0][pos], lds.flag[0][0][pos], lane, G[1][P::A0], G[1][P::A1], G[1][P::A2]);
             if (PE == 1) chain_publish(lds.x[1][0][pos], lds.flag[1][0][pos], lane, G[1][P::B0], G[1][P::B1], G[1][P::B2]);
@@ -171,23 +177,27 @@ struct ChainUnit {
             if ((MASK >> (k - 2)) & 1) { ma[0] = G[k - 1][P::A0]; ma[1] = G[k - 1][P::A1]; ma[2] = G[k - 1][P::A2]; }
             else chain_receive(lds.x[1][k - 2][pos ^ 3], lds.flag[1][k - 2][pos ^ 3], lane, ma, p.stuck);           // RE == k - 1 (positions 1 <-> 2)
             if (RS == k - 1) chain_receive(lds.x[0][k - 2][pos ^ 1], lds.flag[0][k - 2][pos ^ 1], lane, sm[k - 2], p.stuck);
-            if (k == DEPTH) chain_stage<DIR, EMIT, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 2], G[k], mac);
-            else chain_stage<DIR, false, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 2], G[k], mac);
+            if (SPREAD && k == 2) { __builtin_amdgcn_sched_barrier(0); march_load_aligned_part<1>(a, cn, nxt); __builtin_amdgcn_sched_barrier(0); }
+            if (SPREAD && k == 3) { __builtin_amdgcn_sched_barrier(0); march_load_aligned_part<2>(a, cn, nxt); __builtin_amdgcn_sched_barrier(0); }
+            if (k == DEPTH) chain_stage<DIR, EMIT, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 1], 4 * (k - 2), G[k], mac);
+            else chain_stage<DIR, false, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 1], 4 * (k - 2), G[k], mac);
             if (k < DEPTH && PS == k) chain_publish(lds.x[0][k - 1][pos], lds.flag[0][k - 1][pos], lane, G[k][P::A0], G[k][P::A1], G[k][P::A2]);
             if (k < DEPTH && PE == k) chain_publish(lds.x[1][k - 1][pos], lds.flag[1][k - 1][pos], lane, G[k][P::B0], G[k][P::B1], G[k][P::B2]);
         }
         static_assert(RE == 0 || (((MASK >> RE) & 1) && !((MASK >> (RE - 1)) & 1)), "RE names the level below the first stage of a drain iteration");
         if (LAST) {
             pin_after(G[DEPTH]);
-            if (S1) wait_for_column(nxt, hvn[0], hvn[1], DEPTH == 4 ? hvn[DEPTH - 2] : T(0));
+            if (S1) wait_for_column(nxt, hvn);
             const int c = x - (DEPTH - 1) * DIR;
             march3_store<EMIT>(m, a.voff_st, c, G[DEPTH], mac);
             seam3_flush(m, seam_col, sp);
             seam_col = c;
         }
 #pragma unroll
+        for (int k = DEPTH - 1; k > 0; k--) hv[k] = hv[k - 1];
+        hv[0] = hvn;
+#pragma unroll
         for (int k = 1; k < DEPTH; k++) {
-            hv[k - 1] = hvn[k - 1];
             if (!((MASK >> (k - 1)) & 1)) continue;      // level k was not advanced: its carried columns stay
             sm[k - 1][0] = sc[k - 1][P::B0]; sm[k - 1][1] = sc[k - 1][P::B1]; sm[k - 1][2] = sc[k - 1][P::B2];
 #pragma unroll
@@ -216,9 +226,9 @@ struct ChainUnit {
             for (int q = 0; q < 9; q++) sc[k][q] = mv_splat<T, S>(feq0[q]);
             sm[k][0] = sc[k][1]; sm[k][1] = sc[k][5]; sm[k][2] = sc[k][8];
         }
-        march_load_stream(a, xf, in);
+        march_load_aligned(a, xf, in);
 #pragma unroll
-        for (int k = 1; k < DEPTH; k++) hv[k - 1] = halo_load<T>(rh[k - 1], hoff, hcol(xf - k * DIR));
+        for (int k = 0; k < DEPTH; k++) hv[k] = halo_load<T>(rh, hoff, hcol(xf - k * DIR));
         // ---- start seam: iteration q brings level q + 1 of the first column into being and publishes its backward-moving populations; the
         //      partner's forward-moving ones are taken one iteration later, just before the stage that needs them
         iter<1, 0, 1, 0, 0>(xf);
@@ -297,16 +307,11 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     a.voff_st = (j0 < g.ny) ? (unsigned)j0 * EB : p.lat_bytes;
     a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
     a.lane = lane;
-    const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 8u * EB;
-    const __amdgpu_buffer_rsrc_t rh1 = march_rsrc(p.halo, hbytes), rh2 = march_rsrc(p.halo2, hbytes), rh3 = march_rsrc(p.halo3, hbytes);
-    unsigned hoff;
-    {
-        const int hl = lane < 6 ? lane : 0;
-        const int dx = (hl == 1 || hl == 5) ? -1 : ((hl == 2 || hl == 4) ? 1 : 0);
-        const int slot = hl < 3 ? hl : hl + 1;
-        const int seam = hl < 3 ? w : w + 1;
-        hoff = (unsigned)((seam * (g.nxl + 2) + 1 + dx) * 8 + slot) * EB;
-    }
+    // halo lines (step_march3.hpp): lanes 0..15 hold the first half of the line of (seam w, column c) — window w's words from below, levels 1, 2, 3, 0 in
+    // four lanes each —, lanes 16..31 the second half of the line of (seam w+1, column c): its words from above
+    const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * (unsigned)M3_HL * EB;
+    const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.hlines, hbytes);
+    const unsigned hoff = (unsigned)(((w + (lane >= 16 && lane < M3_HL ? 1 : 0)) * (g.nxl + 2) + 1) * M3_HL + (lane < M3_HL ? lane : 0)) * EB;
     {
         // per wave, in elements: below[40] (slot k = the window's last four rows of direction k, staged by the last 4/S lanes; slot
         // 9 stays zero), above[40] (rows 0..3, the first 4/S lanes), then a scratch area for the other lanes' writes
@@ -346,16 +351,15 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
         if (uflags & MU_CHAIN) {
             constexpr int FDP = (DEPTH == 4 && sizeof(T) == 4) ? (FD | MARCH_FD_PACKED) : FD;
             __shared__ ChainLds<T, S, DEPTH> chain_lds;
-            const __amdgpu_buffer_rsrc_t rhs[3] = {rh1, rh2, rh3};
             const bool end_shared = (uflags & MU_END_SHARED) != 0;
             if (lane < 2 * (DEPTH - 1)) chain_lds.flag[lane / (DEPTH - 1)][lane % (DEPTH - 1)][u & 3] = 0;     // my own hand-over flags ...
             __syncthreads();                                                                              // ... before anybody polls them
             if (uflags & MU_DIR_NEG) {
-                ChainUnit<-1, DEPTH, EMIT, FDP, T, S> cu(p, m, rhs, feq0, chain_lds);
+                ChainUnit<-1, DEPTH, EMIT, FDP, T, S> cu(p, m, rh, feq0, chain_lds);
                 cu.hoff = hoff; cu.j0 = j0; cu.lane = lane; cu.pos = u & 3; cu.far_win = far_win;
                 cu.run(ia, ib, end_shared);
             } else {
-                ChainUnit<1, DEPTH, EMIT, FDP, T, S> cu(p, m, rhs, feq0, chain_lds);
+                ChainUnit<1, DEPTH, EMIT, FDP, T, S> cu(p, m, rh, feq0, chain_lds);
                 cu.hoff = hoff; cu.j0 = j0; cu.lane = lane; cu.pos = u & 3; cu.far_win = far_win;
                 cu.run(ia, ib, end_shared);
             }
@@ -364,14 +368,14 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     }
     if (DEPTH == 4) {
         constexpr int FDP = sizeof(T) == 4 ? (FD | MARCH_FD_PACKED) : FD;     // fp32: the packed two-site collision (step_march.hpp)
-        if (lean) march_unit4<false, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
-        else march_unit4<true, EMIT, FDP, T, S>(p, m, rh1, rh2, rh3, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+        if (lean) march_unit4<false, EMIT, FDP, T, S>(p, m, rh, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
+        else march_unit4<true, EMIT, FDP, T, S>(p, m, rh, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     } else if (DEPTH == 3) {
-        if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
-        else march_unit3<true, EMIT, FD, T, S>(p, m, rh1, rh2, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+        if (lean) march_unit3<false, EMIT, FD, T, S>(p, m, rh, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
+        else march_unit3<true, EMIT, FD, T, S>(p, m, rh, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     } else {
-        if (lean) march_unit3_d2<false, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
-        else march_unit3_d2<true, EMIT, FD, T, S>(p, m, rh1, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
+        if (lean) march_unit3_d2<false, EMIT, FD, T, S>(p, m, rh, hoff, ia, ib, uflags, j0, lane, far_win, no_m, no_m, feq0);
+        else march_unit3_d2<true, EMIT, FD, T, S>(p, m, rh, hoff, ia, ib, uflags, j0, lane, far_win, nonfast_m, solid_m, feq0);
     }
 }
 

@@ -283,8 +283,7 @@ struct MarchParams {
     const uint8_t *bcode;      // bounce codes, column 0 first
     const uint8_t *wcls;       // window-tile classes [nwin][nxl + 2]
     const T *halo;             // H[nwin + 1][nxl + 2][8], see k_halo_rows
-    const T *halo2;            // three-step passes only (step_march3.hpp): the level-2 halo table
-    const T *halo3;            // four-step passes only: the level-3 halo table
+    const T *hlines;           // k_march3 (step_march3.hpp): the halo lines HL[nwin + 1][nxl + 2][32], levels 0 .. depth-1 of every (seam, column)
     T *seams;                  // S[nwin + 1][nxl + 2][2][24]: the rows around every window seam of the DESTINATION lattice, see k_halo_from_seams
     const MarchUnit *units;
     int nunits;
@@ -439,6 +438,43 @@ __device__ __forceinline__ void march_load_stream(const MarchAddr<T, S> &a, int 
     fin[4] = bload<T, S>(a.rs, a.voff, lat_off(a, 4, col, 1));
     fin[7] = bload<T, S>(a.rs, a.voff, lat_off(a, 7, col + 1, 1));
     fin[8] = bload<T, S>(a.rs, a.voff, lat_off(a, 8, col - 1, 1));
+}
+
+// The same nine inputs WITHOUT the row shift (k_march3): every load is the window's own 64 S rows of the upstream column — 4 whole 128-byte
+// lines (fp32) instead of 5, the fifth being a line of the neighbouring window that its wave fetches as well.  The shift by one row happens
+// in registers (march_align_in), the row outside the window comes from the column's halo line (level-0 words, step_march3.hpp).
+// Measured before: 46.7 line requests per column and window against 36 + 1 (profiles/r04_u_fetch_calibration.txt).
+template <typename T, int S>
+__device__ __forceinline__ void march_load_aligned(const MarchAddr<T, S> &a, int col, MV<T, S> (&fin)[9])
+{
+    fin[0] = bload<T, S>(a.rs, a.voff, lat_off(a, 0, col, 0));
+    fin[1] = bload<T, S>(a.rs, a.voff, lat_off(a, 1, col - 1, 0));
+    fin[3] = bload<T, S>(a.rs, a.voff, lat_off(a, 3, col + 1, 0));
+    fin[2] = bload<T, S>(a.rs, a.voff, lat_off(a, 2, col, 0));
+    fin[5] = bload<T, S>(a.rs, a.voff, lat_off(a, 5, col - 1, 0));
+    fin[6] = bload<T, S>(a.rs, a.voff, lat_off(a, 6, col + 1, 0));
+    fin[4] = bload<T, S>(a.rs, a.voff, lat_off(a, 4, col, 0));
+    fin[7] = bload<T, S>(a.rs, a.voff, lat_off(a, 7, col + 1, 0));
+    fin[8] = bload<T, S>(a.rs, a.voff, lat_off(a, 8, col - 1, 0));
+}
+
+// ... in three parts of three loads (experiment WT_SPREAD_LOADS: the prefetch issued between the stages instead of in one burst)
+template <int PART, typename T, int S>
+__device__ __forceinline__ void march_load_aligned_part(const MarchAddr<T, S> &a, int col, MV<T, S> (&fin)[9])
+{
+    if (PART == 0) {
+        fin[0] = bload<T, S>(a.rs, a.voff, lat_off(a, 0, col, 0));
+        fin[1] = bload<T, S>(a.rs, a.voff, lat_off(a, 1, col - 1, 0));
+        fin[3] = bload<T, S>(a.rs, a.voff, lat_off(a, 3, col + 1, 0));
+    } else if (PART == 1) {
+        fin[2] = bload<T, S>(a.rs, a.voff, lat_off(a, 2, col, 0));
+        fin[5] = bload<T, S>(a.rs, a.voff, lat_off(a, 5, col - 1, 0));
+        fin[6] = bload<T, S>(a.rs, a.voff, lat_off(a, 6, col + 1, 0));
+    } else {
+        fin[4] = bload<T, S>(a.rs, a.voff, lat_off(a, 4, col, 0));
+        fin[7] = bload<T, S>(a.rs, a.voff, lat_off(a, 7, col + 1, 0));
+        fin[8] = bload<T, S>(a.rs, a.voff, lat_off(a, 8, col - 1, 0));
+    }
 }
 
 // S mask / bounce-code bytes of a lane's sites, site v in bits 8v .. 8v+7
@@ -753,6 +789,17 @@ template <typename T> __device__ __forceinline__ T halo_load(__amdgpu_buffer_rsr
         const u2v x = __builtin_amdgcn_raw_buffer_load_b64(rh, hoff, soff, 0);
         return __hiloint2double((int)x.y, (int)x.x);
     }
+}
+
+// march_load_aligned's inputs of one column -> the streamed (pulled) inputs: populations 2,5,6 come from one row below, 4,7,8 from one row above;
+// `hv` = the column's halo words, level 0 in lanes 12..14 (from below) and 28..30 (from above)
+template <typename T, int S>
+__device__ __forceinline__ void march_align_in(MV<T, S> (&in)[9], int lane, T hv)
+{
+    const T hb2 = readlane_t(hv, 12), hb5 = readlane_t(hv, 13), hb6 = readlane_t(hv, 14), ha4 = readlane_t(hv, 28), ha7 = readlane_t(hv, 29),
+            ha8 = readlane_t(hv, 30);
+    in[2] = m_below(in[2], lane, hb2); in[5] = m_below(in[5], lane, hb5); in[6] = m_below(in[6], lane, hb6);
+    in[4] = m_above(in[4], lane, ha4); in[7] = m_above(in[7], lane, ha7); in[8] = m_above(in[8], lane, ha8);
 }
 
 // Step 1 of column x -> G (all nine directions).  `in` holds the streamed inputs of column x (modified in place).

@@ -25,20 +25,33 @@ namespace wt {
 
 static constexpr int M3_SREC = 80;          // S3 record: 2 halves x (9 slots x 4 rows + one pad slot) elements
 static constexpr int M3_SHALF = 40;
+// Halo LINES (round 4; one table in place of H1 / H2 / H3): HL[(b * (nxl+2) + c + 1) * 32 + 16 side + 4 q + slot], seam b = 1 .. nwin-1 between rows
+// WIN b - 1 and WIN b, column c: everything the stages of the two windows next to the seam need from beyond it for column c, already gathered from
+// the neighbouring columns —
+//     side 0 (window b, from below):   slot 0, 1, 2 = populations 2 of column c, 5 of column c-1, 6 of column c+1 in row WIN b - 1 (they move up),
+//     side 1 (window b-1, from above): slot 0, 1, 2 = populations 4 of column c, 7 of column c+1, 8 of column c-1 in row WIN b (they move down) —
+// q = 0, 1, 2: after one, two, three steps (levels 1 .. depth-1); q = 3: LEVEL 0, the lattice's own rows, so that the populations themselves are
+// loaded without a row shift (march_load_aligned).  One 128-byte line (fp32) per seam and column, written whole by one workgroup of the halo
+// kernel; window w reads the first half of line (w, c) and the second half of line (w+1, c) with ONE load instruction (lanes 0..15 / 16..31) one
+// iteration ahead of the column's first stage and hands the register from stage to stage.  Before, every iteration issued three loads (one per
+// level) by lanes 0..5 that each touched three consecutive 32-byte records of two seams, and six of the nine population loads were shifted by one
+// row and took a fifth line each: 46.7 line requests per column and window where 36 + 2 do (profiles/r04_u_fetch_calibration.txt).
+static constexpr int M3_HL = 32;            // elements of one halo line
+static constexpr int HL_COLS = 60;          // lines (columns) per workgroup of the halo kernels
+static constexpr int H3_COLS = HL_COLS, H4_COLS = HL_COLS;
 
 // ------------------------------------------------------------------------------------------------
-// once per pass: the two halo tables
+// once per pass: the halo lines
 // ------------------------------------------------------------------------------------------------
-// H1 / H2[(b * (nxl+2) + x + 1) * 8 + side * 4 + {0,1,2}], seam b = 1 .. nwin-1 between rows 128 b - 1 and 128 b:
-// side 0 = populations 2,5,6 of row 128 b - 1 (they move up into window b), side 1 = populations 4,7,8 of row 128 b (they move
-// down into window b - 1) — H1 after one step, H2 after two.
-//
-// One block = one seam x 62 columns.  Phase 1: thread (column cl = 0..63, row r4 = 0..3) computes the level-1 populations of
-// site (x0 - 1 + cl, 128 b - 2 + r4) into LDS.  Plain interior fluid sites take their nine inputs from the seam buffer S3
-// (record of the upstream column: rows 128 b - 4 .. 128 b + 3 of the lattice this pass reads) when it is valid; everything
-// else — and every site when it is not — goes through site_step1 on the lattice.  Phase 2: thread (column 1..62, side)
-// applies STEP_FS once more, every branch in the reference's order (html:283-360), to the level-1 values in LDS.
-static constexpr int H3_COLS = 62;          // output columns per block
+// One block = one seam x 60 columns (x0 .. x0+59), NL = depth - 1 levels:
+//   level 1 of rows WIN b - NL .. WIN b + NL - 1 x (60 + 2 NL) columns from the seam buffer S3 (the record of the upstream column: rows
+//           WIN b - 4 .. WIN b + 3 of the lattice this pass reads) where the site is plain interior fluid and S3 is valid, else through
+//           site_step1 on the lattice -> LDS;  the same threads put the LEVEL-0 words of their column into the lines (they ARE three of the
+//           site's nine pulled inputs);
+//   level k of 2 (NL + 1 - k) rows x (60 + 2 (NL + 1 - k)) columns from level k-1 in LDS (halo_step: every branch of STEP_FS in the
+//           reference's order);  the last level stays in registers, 62 columns x the two rows next to the seam;
+//   the 60 lines are put together in LDS and stored as 60 x 128 contiguous bytes.
+// (Every level is computed two columns wider than the next one needs: no word of a line comes from another block.)
 
 // once per mask upload: flags3[(b - 1) * nxl + x], bit r4 set <=> site (x, 128 b - 2 + r4) is plain interior fluid (not solid, no
 // solid neighbour, not on an inlet / outlet column or the first / last row) — one coalesced byte in place of eleven
@@ -62,96 +75,6 @@ __global__ __launch_bounds__(256) void k_seam_flags3(const uint8_t *__restrict__
     }
     flags3[t] = (uint8_t)f;
 }
-
-template <typename T, int S, int FD>
-__global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
-                                               const uint8_t *__restrict__ flags3, T *__restrict__ h1, T *__restrict__ h2, Geom g, int nwin,
-                                               int use_seams, FastDiv fdv, T tau, T U0)
-{
-    constexpr int M3_WIN = 64 * S;
-    __shared__ T l1[64][4][9 + 1];       // [column][row][direction] (+1: spreads the columns over the LDS banks)
-    const int nblk_x = (g.nxl + H3_COLS - 1) / H3_COLS;
-    const int b = 1 + (int)(blockIdx.x / nblk_x);
-    const int x0 = (int)(blockIdx.x % nblk_x) * H3_COLS;
-    const uint8_t *m = mask + g.pitch;
-    {   // ---- phase 1
-        const int cl = threadIdx.x >> 2, r4 = threadIdx.x & 3;
-        const int x = x0 - 1 + cl;
-        const int j = M3_WIN * b - 2 + r4;
-        T o[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) o[k] = T(0);
-        if (x >= 0 && x < g.nxl && j < g.ny) {
-            // the nine seam-buffer inputs are requested together with the flag (not behind it): this kernel is a chain of memory
-            // latencies, and the records of columns x-1 .. x+1 exist for every x (pad records at both ends)
-            T a[9];
-            const T *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const int q = 2 + r4 - ey_of(k);                 // row j - ey_k relative to row 128 b - 4: 1..6
-                a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
-            }
-            const bool plain = use_seams && ((flags3[(long)(b - 1) * g.nxl + x] >> r4) & 1) != 0;
-            if (plain) {
-                T rho, ux, uy;
-                collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
-            } else {
-                site_step1<T, FD>(fs + g.pitch, m, g, x, j, fdv, tau, U0, o);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 9; k++) l1[cl][r4][k] = o[k];
-    }
-    __syncthreads();
-    {   // ---- phase 2
-        const int cl = 1 + (threadIdx.x >> 1), side = threadIdx.x & 1;
-        const int x = x0 - 1 + cl;
-        if (threadIdx.x >= 2 * H3_COLS || x >= g.nxl) return;
-        const int j = M3_WIN * b - 1 + side;
-        const int idx = 1 + side;                               // row of l1 holding row j
-        auto get = [&](int k, int dx, int dy) { return l1[cl + dx][idx + dy][k]; };
-        T o[9];
-        if (j >= g.ny) {
-#pragma unroll
-            for (int k = 0; k < 9; k++) o[k] = T(0);
-        } else {
-            const long c = (long)x * g.pitch + j;
-            const int gi = x + g.gi0;
-            if ((flags3[(long)(b - 1) * g.nxl + x] >> idx) & 1) {          // plain interior fluid: html:324-359 without the mask reads
-                T fin[9], rho, ux, uy;
-#pragma unroll
-                for (int k = 0; k < 9; k++) fin[k] = get(k, -ex_of(k), -ey_of(k));
-                collide_t<T, FD>(fin, fdv, tau, o, rho, ux, uy);
-            } else if (m[c]) {                                             // html:287-294 solid
-#pragma unroll
-                for (int k = 0; k < 9; k++) o[k] = get(opp_of(k), 0, 0);
-            } else if (gi == g.nx_g - 1) {                                 // html:301-312 outlet
-#pragma unroll
-                for (int k = 0; k < 9; k++) o[k] = get(k, -1, 0);
-            } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
-                feq_all<T>(T(1), U0, T(0), o);
-            } else {                                                       // html:324-359 interior fluid
-                T fin[9], rho, ux, uy;
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
-                    fin[k] = m[src] ? get(opp_of(k), 0, 0) : get(k, -ex_of(k), -ey_of(k));
-                }
-                collide_t<T, FD>(fin, fdv, tau, o, rho, ux, uy);
-            }
-        }
-        const long rec = ((long)b * (g.nxl + 2) + x + 1) * 8 + side * 4;
-        typedef T t4 __attribute__((ext_vector_type(4)));
-        const t4 v1 = side ? t4{get(4, 0, 0), get(7, 0, 0), get(8, 0, 0), T(0)} : t4{get(2, 0, 0), get(5, 0, 0), get(6, 0, 0), T(0)};
-        const t4 v2 = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
-        *reinterpret_cast<t4 *>(h1 + rec) = v1;
-        *reinterpret_cast<t4 *>(h2 + rec) = v2;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// FOUR steps per pass: the halo tables H1, H2, H3
-// ------------------------------------------------------------------------------------------------
 // flags4[(b - 1) * nxl + x], bit r6 set <=> site (x, WIN b - 3 + r6) is plain interior fluid (see k_seam_flags3)
 __global__ __launch_bounds__(256) void k_seam_flags4(const uint8_t *__restrict__ mask, const uint8_t *__restrict__ bcode, uint8_t *__restrict__ flags4,
                                                      Geom g, int nwin, int win)
@@ -210,98 +133,163 @@ __device__ __forceinline__ void halo_step(const uint8_t *__restrict__ m, const G
     }
 }
 
-// One block = one seam x 60 columns.  Level 1 of rows WIN b - 3 .. WIN b + 2 (six rows) x 64 columns from the seam buffer / the
-// lattice, level 2 of rows WIN b - 2 .. WIN b + 1 x 62 columns, level 3 of rows WIN b - 1, WIN b x 60 columns, in LDS; H1, H2, H3
-// take the two rows next to the seam of each level (layout as in k_halo3).
-static constexpr int H4_COLS = 60;
 #ifdef WT_UNIT_CLOCKS
-__device__ unsigned long long g_halo_clk[8];      // diagnostic build: clocks of k_halo4's phases, summed over workgroups (+ count)
+__device__ unsigned long long g_halo_clk[8];      // diagnostic build: clocks of the halo kernel's phases, summed over workgroups (+ count)
 #define H4_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_halo_clk[i], t_ - tprev_); tprev_ = t_; } } while (0)
 #else
 #define H4_STAMP(i) do { } while (0)
 #endif
-template <typename T, int S, int FD>
-__global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
-                                               const uint8_t *__restrict__ flags4, T *__restrict__ h1, T *__restrict__ h2, T *__restrict__ h3, Geom g,
-                                               int nwin, int use_seams, FastDiv fdv, T tau, T U0)
+
+// words of line `o`, side `side`, level index q from a level held in LDS: lk[column][row][direction], `c` = the line's column in lk, `r` = the row next
+// to the seam on that side
+template <typename T, typename LK>
+__device__ __forceinline__ void halo_words_from(T (&ol)[HL_COLS][M3_HL], int o, int side, int q, const LK &lk, int c, int r)
 {
-    constexpr int WIN = 64 * S;
-    __shared__ T l1[64][6][9 + 1];
-    __shared__ T l2[64][4][9 + 1];
-    const int nblk_x = (g.nxl + H4_COLS - 1) / H4_COLS;
+    T *w = &ol[o][16 * side + 4 * q];
+    if (side == 0) { w[0] = lk[c][r][2]; w[1] = lk[c - 1][r][5]; w[2] = lk[c + 1][r][6]; }
+    else { w[0] = lk[c][r][4]; w[1] = lk[c + 1][r][7]; w[2] = lk[c - 1][r][8]; }
+    w[3] = T(0);
+}
+
+template <typename T, int S, int FD, int DEPTH>
+__device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
+                                                const uint8_t *__restrict__ flags, T *__restrict__ hl, const Geom &g, int nwin, int use_seams,
+                                                const FastDiv &fdv, T tau, T U0)
+{
+    constexpr int WIN = 64 * S, NL = DEPTH - 1;
+    constexpr int C1 = HL_COLS + 2 * NL, R1 = 2 * NL;                  // level 1: columns x0 - NL + c1, rows WIN b - NL + r
+    constexpr int C2 = HL_COLS + 2 * (NL - 1), R2 = 2 * (NL - 1);      // level 2 (in LDS for DEPTH 4 only): columns x0 - (NL - 1) + c2
+    constexpr int PADK = sizeof(T) == 4 ? 10 : 9;      // fp32: + 1 spreads the columns over the LDS banks; fp64 must stay below 64 KB
+    __shared__ T l1[C1][R1][PADK];
+    __shared__ T l2[DEPTH == 4 ? C2 : 1][DEPTH == 4 ? R2 : 1][9];      // (unpadded: 32736 bytes in all for fp32 — five workgroups per CU)
+    __shared__ __attribute__((aligned(16))) T ol[HL_COLS][M3_HL];
+    const int nblk_x = (g.nxl + HL_COLS - 1) / HL_COLS;
     const int b = 1 + (int)(blockIdx.x / nblk_x);
-    const int x0 = (int)(blockIdx.x % nblk_x) * H4_COLS;          // first output column; l1 / l2 column index cl <-> x0 - 2 + cl
+    const int x0 = (int)(blockIdx.x % nblk_x) * HL_COLS;
     const uint8_t *m = mask + g.pitch;
+    const T *s = fs + g.pitch;                                          // column 0 of the lattice
     typedef T t4 __attribute__((ext_vector_type(4)));
 #ifdef WT_UNIT_CLOCKS
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- level 1: 64 columns x 6 rows
-    for (int w = threadIdx.x; w < 64 * 6; w += 256) {
-        const int cl = w / 6, r6 = w % 6;
-        const int x = x0 - 2 + cl;
-        const int j = WIN * b - 3 + r6;
+    // ---- level 1 (+ the lines' level-0 words)
+    for (int w = threadIdx.x; w < C1 * R1; w += 256) {
+        const int cl = w / R1, r = w % R1;
+        const int x = x0 - NL + cl;
+        const int j = WIN * b - NL + r;
         T o[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = T(0);
         if (x >= 0 && x < g.nxl && j < g.ny) {
+            // the nine seam-buffer inputs are requested together with the flag (not behind it): this kernel is a chain of memory
+            // latencies, and the records of columns x-1 .. x+1 exist for every x (pad records at both ends)
             T a[9];
             const T *rec = seams3 + ((long)b * (g.nxl + 2) + x + 1) * M3_SREC;
 #pragma unroll
             for (int k = 0; k < 9; k++) {
-                const int q = 1 + r6 - ey_of(k);                 // row j - ey_k relative to row WIN b - 4: 0..7
+                const int q = 4 - NL + r - ey_of(k);             // row j - ey_k relative to row WIN b - 4
                 a[k] = rec[-(long)ex_of(k) * M3_SREC + (q >> 2) * M3_SHALF + 4 * k + (q & 3)];
             }
-            const bool plain = use_seams && ((flags4[(long)(b - 1) * g.nxl + x] >> r6) & 1) != 0;
+            const bool plain = use_seams && ((flags[(long)(b - 1) * g.nxl + x] >> r) & 1) != 0;
+            const int o0 = cl - NL;                              // the line of this column
+            if ((r == NL || r == NL - 1) && o0 >= 0 && o0 < HL_COLS) {
+                // level 0: row WIN b (r = NL) pulls populations 2,5,6 out of row WIN b - 1 — window b's words from below; row WIN b - 1 pulls 4,7,8
+                // out of row WIN b — window b-1's words from above.  From the lattice when the seam buffer is stale (first pass after an upload).
+                const bool below = r == NL;
+                T v0 = below ? a[2] : a[4], v1 = below ? a[5] : a[7], v2 = below ? a[6] : a[8];
+                if (!use_seams) {
+                    const long c = (long)x * g.pitch + j;
+                    if (below) { v0 = s[2 * g.plane + c - 1]; v1 = s[5 * g.plane + c - g.pitch - 1]; v2 = s[6 * g.plane + c + g.pitch - 1]; }
+                    else { v0 = s[4 * g.plane + c + 1]; v1 = s[7 * g.plane + c + g.pitch + 1]; v2 = s[8 * g.plane + c - g.pitch + 1]; }
+                }
+                *reinterpret_cast<t4 *>(&ol[o0][(below ? 0 : 16) + 12]) = t4{v0, v1, v2, T(0)};
+            }
             if (plain) {
                 T rho, ux, uy;
                 collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
             } else {
-                site_step1<T, FD>(fs + g.pitch, m, g, x, j, fdv, tau, U0, o);
+                site_step1<T, FD>(s, m, g, x, j, fdv, tau, U0, o);
             }
+        } else {
+            const int o0 = cl - NL;
+            if ((r == NL || r == NL - 1) && o0 >= 0 && o0 < HL_COLS) *reinterpret_cast<t4 *>(&ol[o0][(r == NL ? 0 : 16) + 12]) = t4{T(0), T(0), T(0), T(0)};
         }
 #pragma unroll
-        for (int k = 0; k < 9; k++) l1[cl][r6][k] = o[k];
+        for (int k = 0; k < 9; k++) l1[cl][r][k] = o[k];
     }
     H4_STAMP(0);
     __syncthreads();
     H4_STAMP(1);
-    // ---- level 2: columns cl = 1..62, rows WIN b - 2 + r4
-    if (threadIdx.x < 62 * 4) {
-        const int cl = 1 + threadIdx.x / 4, r4 = threadIdx.x % 4;
-        const int x = x0 - 2 + cl;
-        const int j = WIN * b - 2 + r4;
-        const bool inside = x >= 0 && x < g.nxl;
-        const bool plain = inside && ((flags4[(long)(b - 1) * g.nxl + x] >> (r4 + 1)) & 1) != 0;
-        auto get = [&](int k, int dx, int dy) { return l1[cl + dx][r4 + 1 + dy][k]; };
-        T o[9];
-        halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
+    if constexpr (DEPTH == 4) {
+        // ---- level 2: columns x0 - 2 + c2, rows WIN b - 2 + r (exactly one item per thread)
+        for (int w = threadIdx.x; w < C2 * R2; w += 256) {
+            const int c2 = w / R2, r = w % R2;
+            const int x = x0 - (NL - 1) + c2;
+            const int j = WIN * b - (NL - 1) + r;
+            const bool inside = x >= 0 && x < g.nxl;
+            const bool plain = inside && ((flags[(long)(b - 1) * g.nxl + x] >> (r + 1)) & 1) != 0;
+            auto get = [&](int k, int dx, int dy) { return l1[c2 + 1 + dx][r + 1 + dy][k]; };
+            T o[9];
+            halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
 #pragma unroll
-        for (int k = 0; k < 9; k++) l2[cl][r4][k] = o[k];
+            for (int k = 0; k < 9; k++) l2[c2][r][k] = o[k];
+        }
+        H4_STAMP(2);
+        __syncthreads();
+        H4_STAMP(3);
     }
-    H4_STAMP(2);
-    __syncthreads();
-    H4_STAMP(3);
-    // ---- level 3 and the three tables: columns cl = 2..61, side 0 = row WIN b - 1, side 1 = row WIN b
-    if (threadIdx.x < H4_COLS * 2) {
-        const int cl = 2 + threadIdx.x / 2, side = threadIdx.x & 1;
-        const int x = x0 - 2 + cl;
-        if (x >= g.nxl) return;
+    // ---- the last level (threads 0 .. 123: columns x0 - 1 + c, the two rows next to the seam) beside the lines' words of the levels below it
+    //      (threads 128 .. 247: line o, side)
+    if (threadIdx.x < 2 * (HL_COLS + 2)) {
+        const int c = threadIdx.x >> 1, side = threadIdx.x & 1;
+        const int x = x0 - 1 + c;
         const int j = WIN * b - 1 + side;
-        const bool plain = ((flags4[(long)(b - 1) * g.nxl + x] >> (2 + side)) & 1) != 0;
-        auto get = [&](int k, int dx, int dy) { return l2[cl + dx][1 + side + dy][k]; };
+        const bool inside = x >= 0 && x < g.nxl;
+        const bool plain = inside && ((flags[(long)(b - 1) * g.nxl + x] >> (NL - 1 + side)) & 1) != 0;
         T o[9];
-        halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
-        const long rec = ((long)b * (g.nxl + 2) + x + 1) * 8 + side * 4;
-        const T *p1 = l1[cl][2 + side], *p2 = l2[cl][1 + side];
-        *reinterpret_cast<t4 *>(h1 + rec) = side ? t4{p1[4], p1[7], p1[8], T(0)} : t4{p1[2], p1[5], p1[6], T(0)};
-        *reinterpret_cast<t4 *>(h2 + rec) = side ? t4{p2[4], p2[7], p2[8], T(0)} : t4{p2[2], p2[5], p2[6], T(0)};
-        *reinterpret_cast<t4 *>(h3 + rec) = side ? t4{o[4], o[7], o[8], T(0)} : t4{o[2], o[5], o[6], T(0)};
+        if constexpr (DEPTH == 4) {
+            auto get = [&](int k, int dx, int dy) { return l2[c + 1 + dx][1 + side + dy][k]; };
+            halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
+        } else {
+            auto get = [&](int k, int dx, int dy) { return l1[c + 1 + dx][1 + side + dy][k]; };
+            halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
+        }
+        // own word -> line c-1; the one moving in +x is pulled by column x+1 (line c), the one moving in -x by column x-1 (line c-2)
+        const int q = NL - 1, base = 16 * side + 4 * q;
+        if (c >= 1 && c <= HL_COLS) { ol[c - 1][base] = side ? o[4] : o[2]; ol[c - 1][base + 3] = T(0); }
+        if (c < HL_COLS) ol[c][base + (side ? 2 : 1)] = side ? o[8] : o[5];
+        if (c >= 2) ol[c - 2][base + (side ? 1 : 2)] = side ? o[7] : o[6];
+    } else if (threadIdx.x >= 128 && threadIdx.x < 128 + 2 * HL_COLS) {
+        const int t = threadIdx.x - 128, o = t >> 1, side = t & 1;
+        halo_words_from<T>(ol, o, side, 0, l1, o + NL, NL - 1 + side);
+        if constexpr (DEPTH == 4) halo_words_from<T>(ol, o, side, 1, l2, o + NL - 1, NL - 2 + side);
     }
     H4_STAMP(4);
+    __syncthreads();
+    // ---- the block's lines: contiguous in memory
+    {
+        const int nlines = g.nxl - x0 < HL_COLS ? g.nxl - x0 : HL_COLS;
+        t4 *dst = reinterpret_cast<t4 *>(hl + ((long)b * (g.nxl + 2) + x0 + 1) * M3_HL);
+        const t4 *src = reinterpret_cast<const t4 *>(&ol[0][0]);
+        for (int t = threadIdx.x; t < nlines * (M3_HL / 4); t += 256) dst[t] = src[t];
+    }
+    H4_STAMP(5);
 #ifdef WT_UNIT_CLOCKS
     if (threadIdx.x == 0) atomicAdd(&g_halo_clk[7], 1ULL);
 #endif
+}
+
+template <typename T, int S, int FD>
+__global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
+                                               const uint8_t *__restrict__ flags3, T *__restrict__ hl, Geom g, int nwin, int use_seams, FastDiv fdv, T tau, T U0)
+{
+    halo_lines_body<T, S, FD, 3>(fs, seams3, mask, flags3, hl, g, nwin, use_seams, fdv, tau, U0);
+}
+template <typename T, int S, int FD>
+__global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
+                                               const uint8_t *__restrict__ flags4, T *__restrict__ hl, Geom g, int nwin, int use_seams, FastDiv fdv, T tau, T U0)
+{
+    halo_lines_body<T, S, FD, 4>(fs, seams3, mask, flags4, hl, g, nwin, use_seams, fdv, tau, U0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -325,16 +313,17 @@ struct March3Addr {
 };
 
 // one more application of STEP_FS in registers: level k+1 of column c from level k of columns c-1 (populations 1,5,8: m158),
-// c (all nine: Gc) and c+1 (3,6,7 of Gn); `hv` = this column's halo-table word (lanes 0..5)
+// c (all nine: Gc) and c+1 (3,6,7 of Gn); `hv`, `lb`: this column's halo line (lanes 0..23) and the level's first lane
 template <bool BODY, bool WANT_MACRO, int FD, typename T, int S>
 __device__ __forceinline__ void march_stage(const MarchParams<T> &p, int c, int j0, int lane, bool far_win, bool nf, bool allsolid,
-                                            const T (&feq0)[9], const MV<T, S> (&m158)[3], const MV<T, S> (&Gc)[9], const MV<T, S> (&Gn)[9], T hv,
+                                            const T (&feq0)[9], const MV<T, S> (&m158)[3], const MV<T, S> (&Gc)[9], const MV<T, S> (&Gn)[9], T hv, int lb,
                                             MV<T, S> (&out)[9], MV<T, S> (&mac)[3], const uint32_t *pre = nullptr)
 {
     typedef MV<T, S> V3;
     const Geom &g = p.g;
-    const T hb2 = readlane_t(hv, 0), hb5 = readlane_t(hv, 1), hb6 = readlane_t(hv, 2), ha4 = readlane_t(hv, 3), ha7 = readlane_t(hv, 4),
-                ha8 = readlane_t(hv, 5);
+    // `hv` = this lane's element of column c's halo words, `lb` = 4 (level - 1): the lane of the level's first from-below word (from above: + 16)
+    const T hb2 = readlane_t(hv, lb), hb5 = readlane_t(hv, lb + 1), hb6 = readlane_t(hv, lb + 2), ha4 = readlane_t(hv, lb + 16), ha7 = readlane_t(hv, lb + 17),
+                ha8 = readlane_t(hv, lb + 18);
     V3 fin[9];
     fin[0] = Gc[0]; fin[1] = m158[0]; fin[3] = Gn[3];
     fin[2] = m_below(Gc[2], lane, hb2); fin[5] = m_below(m158[1], lane, hb5); fin[6] = m_below(Gn[6], lane, hb6);
@@ -399,7 +388,7 @@ __device__ __forceinline__ void march3_store(const March3Addr<T, S> &m, unsigned
 // has nothing younger in flight, and the merged counter state keeps that — which also waits for the eleven stores just
 // issued: every iteration then ends by draining its own stores.
 template <typename T, int S>
-__device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1 = T(0), T h2 = T(0), T h3 = T(0))
+__device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1)
 {
 #ifdef WT_M3_NOWAIT          // experiments: leave the waits to hipcc
     return;
@@ -407,7 +396,23 @@ __device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1 = T
     u2v r[9];                // the raw 8 bytes of every vector: the same registers, whatever T and S are
 #pragma unroll
     for (int k = 0; k < 9; k++) __builtin_memcpy(&r[k], &c[k], 8);
-    asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(r[8]), "v"(h1), "v"(h2), "v"(h3));
+    asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(r[8]), "v"(h1));
+}
+template <typename T, int S>
+__device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1, T h2)
+{
+    wait_for_column(c, h1);
+#ifndef WT_M3_NOWAIT
+    asm volatile("" ::"v"(h2));
+#endif
+}
+template <typename T, int S>
+__device__ __forceinline__ void wait_for_column(const MV<T, S> (&c)[9], T h1, T h2, T h3)
+{
+    wait_for_column(c, h1);
+#ifndef WT_M3_NOWAIT
+    asm volatile("" ::"v"(h2), "v"(h3));
+#endif
 }
 __device__ __forceinline__ void wait_for_bytes(const SiteBytes &b)
 {
@@ -444,12 +449,12 @@ __device__ __forceinline__ void seam3_flush(const March3Addr<T, S> &m, int col, 
 }
 
 template <bool BODY, bool EMIT, int FD, typename T, int S>
-__device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, __amdgpu_buffer_rsrc_t rh2, unsigned hoff,
+__device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh, unsigned hoff,
                                             int ia, int ib, int uflags, int j0, int lane, bool far_win, ClassMask nonfast_m,
                                             ClassMask solid_m, const T (&feq0)[9])
 {
     typedef MV<T, S> V3;
-    constexpr unsigned HREC = 8 * sizeof(T);     // bytes of one halo-table record
+    constexpr unsigned HREC = M3_HL * sizeof(T);     // bytes of one halo line
     const Geom &g = p.g;
     const MarchAddr<T, S> &a = m.a;
 #define NONFAST(x) (BODY && cm_bit(nonfast_m, (x) - ia + 2))
@@ -467,23 +472,27 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     for (int k = 0; k < 9; k++) { s1c[k] = mv_splat<T, S>(feq0[k]); s2c[k] = s1c[k]; }
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     s2m[0] = s1c[1]; s2m[1] = s1c[5]; s2m[2] = s1c[8];
+    // halo lines of the columns the first iteration's stages work on (afterwards: one line per iteration, fetched one iteration ahead like the
+    // populations, and handed from stage to stage)
+    T hv2 = halo_load<T>(rh, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * HREC);          // column x-2
+    T hv1 = halo_load<T>(rh, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);          // column x-1
+    T hv0 = halo_load<T>(rh, hoff, (unsigned)ia * HREC);                                 // column x
     if (!BODY || ia - 2 + g.gi0 >= 0) {
-        march_load_stream(a, ia - 2, in);
+        march_load_aligned(a, ia - 2, in);
+        march_align_in(in, lane, hv2);
         STEP1(ia - 2, in, s1c);
     }
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     if (!BODY || ia - 1 + g.gi0 >= 0) {
-        march_load_stream(a, ia - 1, in);
+        march_load_aligned(a, ia - 1, in);
+        march_align_in(in, lane, hv1);
         STEP1(ia - 1, in, s1c);
     }
-    march_load_stream(a, ia, in);
-    // halo-table words of the columns the first iteration produces (fetched one iteration ahead, like the populations)
-    T hv1 = halo_load<T>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);
-    T hv2 = halo_load<T>(rh2, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * HREC);
+    march_load_aligned(a, ia, in);
     // site bytes of columns x, x-1, x-2 (general loop only; see SiteBytes)
     SiteBytes sb0{{0, 0}}, sb1{{0, 0}}, sb2{{0, 0}};
     if (BODY) { sb0 = site_bytes_load<T, S>(p, ia, j0); sb1 = site_bytes_load<T, S>(p, ia - 1, j0); sb2 = site_bytes_load<T, S>(p, ia - 2, j0); wait_for_bytes(sb0); wait_for_bytes(sb1); wait_for_bytes(sb2); }
-    wait_for_column(in, hv1, hv2);      // no load pending at the loop header: see wait_for_column
+    wait_for_column(in, hv0, hv1, hv2);      // no load pending at the loop header: see wait_for_column
     int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
 #ifdef WT_M3_STAMPS
     unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_amdgcn_s_memtime();
@@ -494,34 +503,34 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 #pragma unroll 1
     for (int x = ia; x <= xend; x++) {
         V3 nxt[9];
-        march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);               // prefetch (last one: harmless re-load)
+        march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);              // prefetch (last one: harmless re-load)
         const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
         const int c1 = x - 1, c2 = x - 2;
-        const T hv1n = halo_load<T>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * HREC);
-        const T hv2n = halo_load<T>(rh2, hoff, (unsigned)(c2 + 1 > 0 ? c2 + 1 : 0) * HREC);
+        const T hvn = halo_load<T>(rh, hoff, (unsigned)(x + 1) * HREC);        // column x+1's halo line: the next iteration's first stage
         SiteBytes sbn{{0, 0}};
         if (BODY) sbn = site_bytes_load<T, S>(p, x + 1, j0);
         const Seam3 sp = seam3_fetch(m);                                       // staged by the previous iteration's store
         M3_STAMP(0);                                                           // issue of the prefetch
+        march_align_in(in, lane, hv0);
         STEP1P(x, in, G1, sb0);                                                // level 1 of column x
         M3_STAMP(1);
         // level 2 of column x-1 (a column left of the inlet takes the inlet branch: constants, no memory access)
-        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);
+        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, 0, G2, mac, BODY ? sb1.v : nullptr);
 #ifdef WT_M3_STAMPS
         pin_after(G2);
 #endif
         M3_STAMP(2);
         V3 out[9];
-        march_stage<BODY, EMIT, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, out, mac, BODY ? sb2.v : nullptr);
+        march_stage<BODY, EMIT, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, 4, out, mac, BODY ? sb2.v : nullptr);
         pin_after(out);
         M3_STAMP(3);
-        wait_for_column(nxt, hv1n, hv2n);
+        wait_for_column(nxt, hvn);
         if (BODY) { wait_for_bytes(sbn); sb2 = sb1; sb1 = sb0; sb0 = sbn; }
 #ifdef WT_M3_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         M3_STAMP(4);                                                           // the wait for the prefetched column
-        hv1 = hv1n; hv2 = hv2n;
+        hv2 = hv1; hv1 = hv0; hv0 = hvn;
         march3_store<EMIT>(m, has2 ? a.voff_st : p.lat_bytes, has2 ? c2 : 0, out, mac);
         seam3_flush(m, seam_col, sp);
         M3_STAMP(5);                                                           // issue of the stores
@@ -554,9 +563,9 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         // level 3 of column NX-2
         V3 t2m[3];
         t2m[0] = s2c[1]; t2m[1] = s2c[5]; t2m[2] = s2c[8];
-        const T hv2t = halo_load<T>(rh2, hoff, (unsigned)(co - 1) * HREC);
+        const T hv2t = halo_load<T>(rh, hoff, (unsigned)(co - 1) * HREC);
         Seam3 sp = seam3_fetch(m);
-        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2t, out, mac);
+        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2t, 4, out, mac);
         march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = co - 1;
@@ -581,12 +590,12 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 // (level 2 of column ia-2 is needed) and delivers level 4 of column x-3.  Columns ia-3 .. ib+2 take part: class masks are indexed
 // by x - ia + 3.
 template <bool BODY, bool EMIT, int FD, typename T, int S>
-__device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, __amdgpu_buffer_rsrc_t rh2,
-                                            __amdgpu_buffer_rsrc_t rh3, unsigned hoff, int ia, int ib, int uflags, int j0, int lane, bool far_win,
+__device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh,
+                                            unsigned hoff, int ia, int ib, int uflags, int j0, int lane, bool far_win,
                                             ClassMask nonfast_m, ClassMask solid_m, const T (&feq0)[9])
 {
     typedef MV<T, S> V3;
-    constexpr unsigned HREC = 8 * sizeof(T);
+    constexpr unsigned HREC = M3_HL * sizeof(T);
     const Geom &g = p.g;
     const MarchAddr<T, S> &a = m.a;
     // (the level-4 stage of the first iteration works on column ia-4, outside the masks: no class -> plain / inlet branch, no mask access)
@@ -606,46 +615,52 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     s2m[0] = s1c[1]; s2m[1] = s1c[5]; s2m[2] = s1c[8];
     s3m[0] = s1c[1]; s3m[1] = s1c[5]; s3m[2] = s1c[8];
     // ---- prologue: level 1 of columns ia-3 and ia-2 (columns left of the inlet do not exist: the far-field value stands in)
+    const int xs = ia - 1;       // first loop column; when it lies left of the inlet its loads go to the inlet column (values unused)
+#define LCOL(x) ((BODY && (x) + g.gi0 < 0) ? -g.gi0 : (x))
+    // halo lines of columns x-3, x-2, x-1, x (afterwards: one line per iteration, fetched one iteration ahead, handed from stage to stage)
+    T hv3 = halo_load<T>(rh, hoff, HCOL(xs - 3)), hv2 = halo_load<T>(rh, hoff, HCOL(xs - 2)), hv1 = halo_load<T>(rh, hoff, HCOL(xs - 1)),
+      hv0 = halo_load<T>(rh, hoff, HCOL(xs));
     if (!BODY || ia - 3 + g.gi0 >= 0) {
-        march_load_stream(a, ia - 3, in);
+        march_load_aligned(a, ia - 3, in);
+        march_align_in(in, lane, hv2);          // ia - 3 = xs - 2
         STEP1(ia - 3, in, s1c);
     }
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     if (!BODY || ia - 2 + g.gi0 >= 0) {
-        march_load_stream(a, ia - 2, in);
+        march_load_aligned(a, ia - 2, in);
+        march_align_in(in, lane, hv1);          // ia - 2 = xs - 1
         STEP1(ia - 2, in, s1c);
     }
-    const int xs = ia - 1;       // first loop column; when it lies left of the inlet its loads go to the inlet column (values unused)
-#define LCOL(x) ((BODY && (x) + g.gi0 < 0) ? -g.gi0 : (x))
-    march_load_stream(a, LCOL(xs), in);
-    T hv1 = halo_load<T>(rh1, hoff, HCOL(xs - 1)), hv2 = halo_load<T>(rh2, hoff, HCOL(xs - 2)), hv3 = halo_load<T>(rh3, hoff, HCOL(xs - 3));
+    march_load_aligned(a, LCOL(xs), in);
     // site bytes of columns x, x-1, x-2, x-3 (general loop only; see SiteBytes)
     SiteBytes sb0{{0, 0}}, sb1{{0, 0}}, sb2{{0, 0}}, sb3{{0, 0}};
     if (BODY) {
         sb0 = site_bytes_load<T, S>(p, xs, j0); sb1 = site_bytes_load<T, S>(p, xs - 1, j0); sb2 = site_bytes_load<T, S>(p, xs - 2, j0); sb3 = site_bytes_load<T, S>(p, xs - 3, j0);
         wait_for_bytes(sb0); wait_for_bytes(sb1); wait_for_bytes(sb2); wait_for_bytes(sb3);
     }
-    wait_for_column(in, hv1, hv2, hv3);
+    wait_for_column(in, hv0, hv1, hv2);
+    wait_for_column(in, hv3);
     int seam_col = -1;
 #pragma unroll 1
     for (int x = xs; x <= xend; x++) {
         V3 nxt[9];
-        march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);
+        march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has3 = x - 3 >= ia;                                         // column x-3 is an output column
         const int c1 = x - 1, c2 = x - 2, c3 = x - 3;
-        const T hv1n = halo_load<T>(rh1, hoff, HCOL(c1 + 1)), hv2n = halo_load<T>(rh2, hoff, HCOL(c2 + 1)), hv3n = halo_load<T>(rh3, hoff, HCOL(c3 + 1));
+        const T hvn = halo_load<T>(rh, hoff, HCOL(x + 1));                      // column x+1's halo line: the next iteration's first stage
         SiteBytes sbn{{0, 0}};
         if (BODY) sbn = site_bytes_load<T, S>(p, x + 1, j0);
         const Seam3 sp = seam3_fetch(m);
+        march_align_in(in, lane, hv0);
         march_step1<BODY, FD, T, S>(p, a, x, j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G1, BODY ? sb0.v : nullptr);      // level 1 of column x
-        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);     // level 2 of x-1
-        march_stage<BODY, false, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, G3, mac, BODY ? sb2.v : nullptr);     // level 3 of x-2
+        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, 0, G2, mac, BODY ? sb1.v : nullptr);     // level 2 of x-1
+        march_stage<BODY, false, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, 4, G3, mac, BODY ? sb2.v : nullptr);     // level 3 of x-2
         V3 out[9];
-        march_stage<BODY, EMIT, FD>(p, c3, j0, lane, far_win, NONFAST(c3), ALLSOLID(c3), feq0, s3m, s3c, G3, hv3, out, mac, BODY ? sb3.v : nullptr);     // level 4 of x-3
+        march_stage<BODY, EMIT, FD>(p, c3, j0, lane, far_win, NONFAST(c3), ALLSOLID(c3), feq0, s3m, s3c, G3, hv3, 8, out, mac, BODY ? sb3.v : nullptr);     // level 4 of x-3
         pin_after(out);
-        wait_for_column(nxt, hv1n, hv2n, hv3n);
+        wait_for_column(nxt, hvn);
         if (BODY) { wait_for_bytes(sbn); sb3 = sb2; sb2 = sb1; sb1 = sb0; sb0 = sbn; }
-        hv1 = hv1n; hv2 = hv2n; hv3 = hv3n;
+        hv3 = hv2; hv2 = hv1; hv1 = hv0; hv0 = hvn;
         march3_store<EMIT>(m, has3 ? a.voff_st : p.lat_bytes, has3 ? c3 : 0, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = has3 ? c3 : seam_col;
@@ -671,7 +686,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         if (any_solid) { auto own = [&](int k) { return G1[k]; }; march_solid<T, S, false>(O2, mac, solid4, own); }
         // level 3 of co-1
         tm[0] = s2c[1]; tm[1] = s2c[5]; tm[2] = s2c[8];
-        march_stage<BODY, false, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, G2, O2, halo_load<T>(rh2, hoff, HCOL(co - 1)), L3a, mac);
+        march_stage<BODY, false, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, G2, O2, halo_load<T>(rh, hoff, HCOL(co - 1)), 4, L3a, mac);
         // level 3 of co
 #pragma unroll
         for (int k = 0; k < 9; k++) O3[k] = G2[k];
@@ -681,14 +696,14 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         Seam3 sp = seam3_fetch(m);
         // (a last unit of a single marched column does not own column co-2, and its level 3 of co-3 is not valid: drop the stores)
         const bool own2 = co - 2 >= ia;
-        march_stage<BODY, EMIT, FD>(p, co - 2, j0, lane, far_win, NONFAST(co - 2), ALLSOLID(co - 2), feq0, tm, G3, L3a, halo_load<T>(rh3, hoff, HCOL(co - 2)), out, mac);
+        march_stage<BODY, EMIT, FD>(p, co - 2, j0, lane, far_win, NONFAST(co - 2), ALLSOLID(co - 2), feq0, tm, G3, L3a, halo_load<T>(rh, hoff, HCOL(co - 2)), 8, out, mac);
         march3_store<EMIT>(m, own2 ? a.voff_st : p.lat_bytes, own2 ? co - 2 : 0, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = own2 ? co - 2 : seam_col;
         // level 4 of co-1
         tm[0] = G3[1]; tm[1] = G3[5]; tm[2] = G3[8];
         sp = seam3_fetch(m);
-        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, L3a, O3, halo_load<T>(rh3, hoff, HCOL(co - 1)), out, mac);
+        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, L3a, O3, halo_load<T>(rh, hoff, HCOL(co - 1)), 8, out, mac);
         march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = co - 1;
@@ -713,12 +728,12 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
 // The same machinery stopped after level 2: TWO steps per pass on the tables of the three-step plan (units, classes, H1, seam
 // buffer S3), for the one or two steps a step count leaves over after its three-step passes.
 template <bool BODY, bool EMIT, int FD, typename T, int S>
-__device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh1, unsigned hoff, int ia, int ib,
+__device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh, unsigned hoff, int ia, int ib,
                                                int uflags, int j0, int lane, bool far_win, ClassMask nonfast_m, ClassMask solid_m,
                                                const T (&feq0)[9])
 {
     typedef MV<T, S> V3;
-    constexpr unsigned HREC = 8 * sizeof(T);
+    constexpr unsigned HREC = M3_HL * sizeof(T);
     const Geom &g = p.g;
     const MarchAddr<T, S> &a = m.a;
 #define NONFAST(x) (BODY && cm_bit(nonfast_m, (x) - ia + 2))
@@ -731,28 +746,30 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Ad
 #pragma unroll
     for (int k = 0; k < 9; k++) s1c[k] = mv_splat<T, S>(feq0[k]);
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
+    T hv1 = halo_load<T>(rh, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC), hv0 = halo_load<T>(rh, hoff, (unsigned)ia * HREC);
     if (!BODY || ia - 1 + g.gi0 >= 0) {
-        march_load_stream(a, ia - 1, in);
+        march_load_aligned(a, ia - 1, in);
+        march_align_in(in, lane, hv1);
         STEP1(ia - 1, in, s1c);
     }
-    march_load_stream(a, ia, in);
-    T hv1 = halo_load<T>(rh1, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);
-    wait_for_column(in, hv1);
+    march_load_aligned(a, ia, in);
+    wait_for_column(in, hv0, hv1);
     int seam_col = -1;
 #pragma unroll 1
     for (int x = ia; x <= xend; x++) {
         V3 nxt[9];
-        march_load_stream(a, (x + 1 <= xend) ? x + 1 : x, nxt);
+        march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has1 = x - 1 >= ia;                                         // column x-1 is an output column
         const int c1 = x - 1;
-        const T hv1n = halo_load<T>(rh1, hoff, (unsigned)(c1 + 1 > 0 ? c1 + 1 : 0) * HREC);
+        const T hvn = halo_load<T>(rh, hoff, (unsigned)(x + 1) * HREC);
         const Seam3 sp = seam3_fetch(m);
+        march_align_in(in, lane, hv0);
         STEP1(x, in, G1);
         V3 out[9];
-        march_stage<BODY, EMIT, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, out, mac);
+        march_stage<BODY, EMIT, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, 0, out, mac);
         pin_after(out);
-        wait_for_column(nxt, hv1n);
-        hv1 = hv1n;
+        wait_for_column(nxt, hvn);
+        hv1 = hv0; hv0 = hvn;
         march3_store<EMIT>(m, has1 ? a.voff_st : p.lat_bytes, has1 ? c1 : 0, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = has1 ? c1 : seam_col;

@@ -124,8 +124,7 @@ struct wt_handle {
     int pass_cap = 0;                    // longest pass actually taken on those tables (0 = march_depth): fp64 with fuse_depth = 2
     int tau_cap = 0;                     // fp32, set per stepping call: 3 when the fast division by tau is not proved for this tau (IEEE division:
                                          // the four-step kernel would spill registers and is not built for it), else 0
-    void *halo2 = nullptr;               // depth 3 / 4: level-2 halo table
-    void *halo3 = nullptr;               // depth 4: level-3 halo table
+    void *hlines = nullptr;              // depth 3 / 4: the halo lines of k_march3 (step_march3.hpp), one 32-element line per (window, column)
     long long passes = 0;
     long long single_steps = 0;          // k_step launches of whole steps (option "single_steps"): what a fused plan falls back to
     long long march_table_bytes = 0;     // wcls + halo_tab + seams + seam_plain (part of device_bytes)
@@ -492,8 +491,7 @@ static void free_march_tables(wt_handle *h)
     if (h->halo_tab) { (void)hipFree(h->halo_tab); h->halo_tab = nullptr; }
     if (h->seams) { (void)hipFree(h->seams); h->seams = nullptr; }
     if (h->seam_plain) { (void)hipFree(h->seam_plain); h->seam_plain = nullptr; }
-    if (h->halo2) { (void)hipFree(h->halo2); h->halo2 = nullptr; }
-    if (h->halo3) { (void)hipFree(h->halo3); h->halo3 = nullptr; }
+    if (h->hlines) { (void)hipFree(h->hlines); h->hlines = nullptr; }
     h->seams_valid = false;
     h->n_win = 0;
     h->device_bytes -= h->march_table_bytes;
@@ -582,7 +580,7 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     if (h->n_win != nwin || h->march_s != sites || h->march_depth != depth) free_march_tables(h);
     long long added = 0;
     if (!h->wcls) { HIP_TRY(hipMalloc((void **)&h->wcls, wbytes)); added += (long long)wbytes; }
-    if (!h->halo_tab) {
+    if (depth < 3 && !h->halo_tab) {      // the two-step kernel's table (k_halo_rows / k_halo_from_seams)
         const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb;
         HIP_TRY(hipMalloc(&h->halo_tab, hbytes));
         HIP_TRY(hipMemsetAsync(h->halo_tab, 0, hbytes, h->s_compute));
@@ -596,16 +594,10 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
         added += (long long)sbytes;
     }
     if (!h->seam_plain && nwin > 1) { HIP_TRY(hipMalloc((void **)&h->seam_plain, (size_t)(nwin - 1) * g.nxl)); added += (long long)(nwin - 1) * g.nxl; }
-    if (depth >= 3 && !h->halo2) {
-        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb;
-        HIP_TRY(hipMalloc(&h->halo2, hbytes));
-        HIP_TRY(hipMemsetAsync(h->halo2, 0, hbytes, h->s_compute));
-        added += (long long)hbytes;
-    }
-    if (depth == 4 && !h->halo3) {
-        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * 8 * eb;
-        HIP_TRY(hipMalloc(&h->halo3, hbytes));
-        HIP_TRY(hipMemsetAsync(h->halo3, 0, hbytes, h->s_compute));
+    if (depth >= 3 && !h->hlines) {       // k_march3's halo lines: zeroed once — the slots nobody writes (the lattice's first / last column, the
+        const size_t hbytes = (size_t)(nwin + 1) * (g.nxl + 2) * M3_HL * eb;       // bottom / top window) must stay finite don't-cares
+        HIP_TRY(hipMalloc(&h->hlines, hbytes));
+        HIP_TRY(hipMemsetAsync(h->hlines, 0, hbytes, h->s_compute));
         added += (long long)hbytes;
     }
     h->march_table_bytes += added;
@@ -1364,7 +1356,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.fd = fptr<T>(h, 1 - h->cur);
     p.macro = reinterpret_cast<T *>(h->macro);
     p.mask = h->mask; p.bcode = h->bcode; p.wcls = h->wcls;
-    p.halo = reinterpret_cast<const T *>(h->halo_tab); p.halo2 = reinterpret_cast<const T *>(h->halo2); p.halo3 = reinterpret_cast<const T *>(h->halo3);
+    p.halo = nullptr; p.hlines = reinterpret_cast<const T *>(h->hlines);
     p.seams = reinterpret_cast<T *>(h->seams);
     p.g = g;
     p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(T));
@@ -1383,12 +1375,12 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
         if (h->march_depth == 4) {      // the plan's tables are those of the four-step pass, whatever this pass advances
             const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H4_COLS - 1) / H4_COLS);
             hipLaunchKernelGGL((k_halo4<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
-                               reinterpret_cast<T *>(h->halo_tab), reinterpret_cast<T *>(h->halo2), reinterpret_cast<T *>(h->halo3), g, h->n_win,
+                               reinterpret_cast<T *>(h->hlines), g, h->n_win,
                                h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
         } else {
             const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H3_COLS - 1) / H3_COLS);
             hipLaunchKernelGGL((k_halo3<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
-                               reinterpret_cast<T *>(h->halo_tab), reinterpret_cast<T *>(h->halo2), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
+                               reinterpret_cast<T *>(h->hlines), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
         }
     }
     p.units = h->d_units; p.nunits = h->n_units;

@@ -16,8 +16,8 @@ with pkg.Engine(nx, ny) as e:
     e.step(160, 0.58, 0.06); e.sync()
     lib.wt_debug_halo_clocks(out, 0)
     v = [int(x) for x in out]; n = max(1, v[7])
-    names = ["level 1 (loads + collision + LDS)", "barrier 1", "level 2", "barrier 2", "level 3 + stores"]
+    names = ["level 1 + level-0 words (loads, collision, LDS)", "barrier 1", "level 2", "barrier 2", "level 3 + the lines' words in LDS", "barrier 3 + the lines' store"]
     print(f"{nx}x{ny}: {n} workgroups of k_halo4 in 40 passes; clocks of thread 0 per workgroup:")
-    for nm, c in zip(names, v[:5]):
+    for nm, c in zip(names, v[:6]):
         print(f"  {nm:36s} {c / n:9.0f}")
-    print(f"  total {sum(v[:5]) / n:.0f} clocks = {sum(v[:5]) / n / 2.4e3:.2f} us at 2.4 GHz")
+    print(f"  total {sum(v[:6]) / n:.0f} clocks = {sum(v[:6]) / n / 2.4e3:.2f} us at 2.4 GHz")
