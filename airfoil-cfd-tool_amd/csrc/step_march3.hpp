@@ -135,7 +135,7 @@ __device__ __forceinline__ void halo_step(const uint8_t *__restrict__ m, const G
 
 #ifdef WT_UNIT_CLOCKS
 __device__ unsigned long long g_halo_clk[8];      // diagnostic build: clocks of the halo kernel's phases, summed over workgroups (+ count)
-#define H4_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_halo_clk[i], t_ - tprev_); tprev_ = t_; } } while (0)
+#define H4_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); hst_[i] = t_ - tprev_; tprev_ = t_; } while (0)      // (summed at the end of the kernel)
 #else
 #define H4_STAMP(i) do { } while (0)
 #endif
@@ -170,8 +170,19 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
     const T *s = fs + g.pitch;                                          // column 0 of the lattice
     typedef T t4 __attribute__((ext_vector_type(4)));
 #ifdef WT_UNIT_CLOCKS
-    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+    unsigned long long hst_[7] = {0, 0, 0, 0, 0, 0, 0}, tprev_ = __builtin_amdgcn_s_memtime();
 #endif
+    // the plain-fluid flags of the columns this thread works on in the LATER phases are requested now, beside level 1's inputs: fetched where they
+    // are used they put a trip to memory behind every barrier of a kernel that is a chain of latencies
+    unsigned fl2 = 0, fl3 = 0;
+    if constexpr (DEPTH == 4) {
+        const int x = x0 - (NL - 1) + (int)threadIdx.x / R2;
+        if (x >= 0 && x < g.nxl) fl2 = flags[(long)(b - 1) * g.nxl + x];
+    }
+    if (threadIdx.x < 2 * (HL_COLS + 2)) {
+        const int x = x0 - 1 + (int)(threadIdx.x >> 1);
+        if (x >= 0 && x < g.nxl) fl3 = flags[(long)(b - 1) * g.nxl + x];
+    }
     // ---- level 1 (+ the lines' level-0 words)
     for (int w = threadIdx.x; w < C1 * R1; w += 256) {
         const int cl = w / R1, r = w % R1;
@@ -222,12 +233,12 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
     H4_STAMP(1);
     if constexpr (DEPTH == 4) {
         // ---- level 2: columns x0 - 2 + c2, rows WIN b - 2 + r (exactly one item per thread)
+        static_assert(DEPTH != 4 || C2 * R2 == 256, "one level-2 item per thread");
         for (int w = threadIdx.x; w < C2 * R2; w += 256) {
             const int c2 = w / R2, r = w % R2;
             const int x = x0 - (NL - 1) + c2;
             const int j = WIN * b - (NL - 1) + r;
-            const bool inside = x >= 0 && x < g.nxl;
-            const bool plain = inside && ((flags[(long)(b - 1) * g.nxl + x] >> (r + 1)) & 1) != 0;
+            const bool plain = ((fl2 >> (r + 1)) & 1) != 0;              // (C2 R2 = 256: this thread's one item is the column fl2 was fetched for)
             auto get = [&](int k, int dx, int dy) { return l1[c2 + 1 + dx][r + 1 + dy][k]; };
             T o[9];
             halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
@@ -244,8 +255,7 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
         const int c = threadIdx.x >> 1, side = threadIdx.x & 1;
         const int x = x0 - 1 + c;
         const int j = WIN * b - 1 + side;
-        const bool inside = x >= 0 && x < g.nxl;
-        const bool plain = inside && ((flags[(long)(b - 1) * g.nxl + x] >> (NL - 1 + side)) & 1) != 0;
+        const bool plain = ((fl3 >> (NL - 1 + side)) & 1) != 0;
         T o[9];
         if constexpr (DEPTH == 4) {
             auto get = [&](int k, int dx, int dy) { return l2[c + 1 + dx][1 + side + dy][k]; };
@@ -275,7 +285,10 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
     }
     H4_STAMP(5);
 #ifdef WT_UNIT_CLOCKS
-    if (threadIdx.x == 0) atomicAdd(&g_halo_clk[7], 1ULL);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 7; i++) atomicAdd(&g_halo_clk[i], hst_[i]);
+        atomicAdd(&g_halo_clk[7], 1ULL);
+    }
 #endif
 }
 
