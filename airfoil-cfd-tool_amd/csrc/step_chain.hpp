@@ -152,14 +152,7 @@ struct ChainUnit {
         const MarchAddr<T, S> &a = m.a;
         constexpr bool S1 = (MASK & 1) != 0, LAST = (MASK >> (DEPTH - 1)) != 0;
         V3 nxt[9];
-#ifdef WT_SPREAD_LOADS
-        constexpr bool SPREAD = S1 && DEPTH >= 3 && MASK == FULL;
-#else
-        constexpr bool SPREAD = false;
-#endif
-        const int cn = clampx(x + DIR);
-        if (S1 && !SPREAD) march_load_aligned(a, cn, nxt);
-        if (SPREAD) march_load_aligned_part<0>(a, cn, nxt);
+        if (S1) march_load_aligned(a, clampx(x + DIR), nxt);
         const T hvn = halo_load<T>(rh, hoff, hcol(x + DIR));    // column x + DIR's halo line: the next iteration's stage 1, then handed on
         Seam3 sp;
         if (LAST) sp = seam3_fetch(m);
@@ -177,8 +170,6 @@ struct ChainUnit {
             if ((MASK >> (k - 2)) & 1) { ma[0] = G[k - 1][P::A0]; ma[1] = G[k - 1][P::A1]; ma[2] = G[k - 1][P::A2]; }
             else chain_receive(lds.x[1][k - 2][pos ^ 3], lds.flag[1][k - 2][pos ^ 3], lane, ma, p.stuck);           // RE == k - 1 (positions 1 <-> 2)
             if (RS == k - 1) chain_receive(lds.x[0][k - 2][pos ^ 1], lds.flag[0][k - 2][pos ^ 1], lane, sm[k - 2], p.stuck);
-            if (SPREAD && k == 2) { __builtin_amdgcn_sched_barrier(0); march_load_aligned_part<1>(a, cn, nxt); __builtin_amdgcn_sched_barrier(0); }
-            if (SPREAD && k == 3) { __builtin_amdgcn_sched_barrier(0); march_load_aligned_part<2>(a, cn, nxt); __builtin_amdgcn_sched_barrier(0); }
             if (k == DEPTH) chain_stage<DIR, EMIT, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 1], 4 * (k - 2), G[k], mac);
             else chain_stage<DIR, false, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 1], 4 * (k - 2), G[k], mac);
             if (k < DEPTH && PS == k) chain_publish(lds.x[0][k - 1][pos], lds.flag[0][k - 1][pos], lane, G[k][P::A0], G[k][P::A1], G[k][P::A2]);

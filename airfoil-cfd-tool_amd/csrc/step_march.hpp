@@ -458,25 +458,6 @@ __device__ __forceinline__ void march_load_aligned(const MarchAddr<T, S> &a, int
     fin[8] = bload<T, S>(a.rs, a.voff, lat_off(a, 8, col - 1, 0));
 }
 
-// ... in three parts of three loads (experiment WT_SPREAD_LOADS: the prefetch issued between the stages instead of in one burst)
-template <int PART, typename T, int S>
-__device__ __forceinline__ void march_load_aligned_part(const MarchAddr<T, S> &a, int col, MV<T, S> (&fin)[9])
-{
-    if (PART == 0) {
-        fin[0] = bload<T, S>(a.rs, a.voff, lat_off(a, 0, col, 0));
-        fin[1] = bload<T, S>(a.rs, a.voff, lat_off(a, 1, col - 1, 0));
-        fin[3] = bload<T, S>(a.rs, a.voff, lat_off(a, 3, col + 1, 0));
-    } else if (PART == 1) {
-        fin[2] = bload<T, S>(a.rs, a.voff, lat_off(a, 2, col, 0));
-        fin[5] = bload<T, S>(a.rs, a.voff, lat_off(a, 5, col - 1, 0));
-        fin[6] = bload<T, S>(a.rs, a.voff, lat_off(a, 6, col + 1, 0));
-    } else {
-        fin[4] = bload<T, S>(a.rs, a.voff, lat_off(a, 4, col, 0));
-        fin[7] = bload<T, S>(a.rs, a.voff, lat_off(a, 7, col + 1, 0));
-        fin[8] = bload<T, S>(a.rs, a.voff, lat_off(a, 8, col - 1, 0));
-    }
-}
-
 // S mask / bounce-code bytes of a lane's sites, site v in bits 8v .. 8v+7
 template <int S> __device__ __forceinline__ uint32_t load_site_bytes(const uint8_t *p)
 {
