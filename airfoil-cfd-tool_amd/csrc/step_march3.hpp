@@ -140,17 +140,6 @@ __device__ unsigned long long g_halo_clk[8];      // diagnostic build: clocks of
 #define H4_STAMP(i) do { } while (0)
 #endif
 
-// words of line `o`, side `side`, level index q from a level held in LDS: lk[column][row][direction], `c` = the line's column in lk, `r` = the row next
-// to the seam on that side
-template <typename T, typename LK>
-__device__ __forceinline__ void halo_words_from(T (&ol)[HL_COLS][M3_HL], int o, int side, int q, const LK &lk, int c, int r)
-{
-    T *w = &ol[o][16 * side + 4 * q];
-    if (side == 0) { w[0] = lk[c][r][2]; w[1] = lk[c - 1][r][5]; w[2] = lk[c + 1][r][6]; }
-    else { w[0] = lk[c][r][4]; w[1] = lk[c + 1][r][7]; w[2] = lk[c - 1][r][8]; }
-    w[3] = T(0);
-}
-
 template <typename T, int S, int FD, int DEPTH>
 __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
                                                 const uint8_t *__restrict__ flags, T *__restrict__ hl, const Geom &g, int nwin, int use_seams,
@@ -160,9 +149,12 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
     constexpr int C1 = HL_COLS + 2 * NL, R1 = 2 * NL;                  // level 1: columns x0 - NL + c1, rows WIN b - NL + r
     constexpr int C2 = HL_COLS + 2 * (NL - 1), R2 = 2 * (NL - 1);      // level 2 (in LDS for DEPTH 4 only): columns x0 - (NL - 1) + c2
     constexpr int PADK = sizeof(T) == 4 ? 10 : 9;      // fp32: + 1 spreads the columns over the LDS banks; fp64 must stay below 64 KB
-    __shared__ T l1[C1][R1][PADK];
-    __shared__ T l2[DEPTH == 4 ? C2 : 1][DEPTH == 4 ? R2 : 1][9];      // (unpadded: 32736 bytes in all for fp32 — five workgroups per CU)
-    __shared__ __attribute__((aligned(16))) T ol[HL_COLS][M3_HL];
+    __shared__ __attribute__((aligned(32))) T l1[C1][R1][PADK];
+    __shared__ T l2[DEPTH == 4 ? C2 : 1][DEPTH == 4 ? R2 : 1][9];
+    __shared__ __attribute__((aligned(32))) T lv0[HL_COLS][2][4];      // level-0 words until the lines are put together
+    // the 60 lines are put together in l1's memory once nobody reads it any more (behind the third barrier): fp64 stays at three workgroups per CU
+    static_assert(sizeof(T) * C1 * R1 * PADK >= sizeof(T) * HL_COLS * M3_HL, "the lines fit into l1");
+    T (*ol)[M3_HL] = reinterpret_cast<T (*)[M3_HL]>(&l1[0][0][0]);
     const int nblk_x = (g.nxl + HL_COLS - 1) / HL_COLS;
     const int b = 1 + (int)(blockIdx.x / nblk_x);
     const int x0 = (int)(blockIdx.x % nblk_x) * HL_COLS;
@@ -213,7 +205,7 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
                     if (below) { v0 = s[2 * g.plane + c - 1]; v1 = s[5 * g.plane + c - g.pitch - 1]; v2 = s[6 * g.plane + c + g.pitch - 1]; }
                     else { v0 = s[4 * g.plane + c + 1]; v1 = s[7 * g.plane + c + g.pitch + 1]; v2 = s[8 * g.plane + c - g.pitch + 1]; }
                 }
-                *reinterpret_cast<t4 *>(&ol[o0][(below ? 0 : 16) + 12]) = t4{v0, v1, v2, T(0)};
+                *reinterpret_cast<t4 *>(&lv0[o0][below ? 0 : 1][0]) = t4{v0, v1, v2, T(0)};
             }
             if (plain) {
                 T rho, ux, uy;
@@ -223,7 +215,7 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
             }
         } else {
             const int o0 = cl - NL;
-            if ((r == NL || r == NL - 1) && o0 >= 0 && o0 < HL_COLS) *reinterpret_cast<t4 *>(&ol[o0][(r == NL ? 0 : 16) + 12]) = t4{T(0), T(0), T(0), T(0)};
+            if ((r == NL || r == NL - 1) && o0 >= 0 && o0 < HL_COLS) *reinterpret_cast<t4 *>(&lv0[o0][r == NL ? 0 : 1][0]) = t4{T(0), T(0), T(0), T(0)};
         }
 #pragma unroll
         for (int k = 0; k < 9; k++) l1[cl][r][k] = o[k];
@@ -250,8 +242,11 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
         H4_STAMP(3);
     }
     // ---- the last level (threads 0 .. 123: columns x0 - 1 + c, the two rows next to the seam) beside the lines' words of the levels below it
-    //      (threads 128 .. 247: line o, side)
-    if (threadIdx.x < 2 * (HL_COLS + 2)) {
+    //      (threads 128 .. 247: line o, side): into registers first — the lines take l1's place
+    T wl[3] = {T(0), T(0), T(0)};                 // last level: own word, the one moving in +x, the one moving in -x
+    t4 wq[3];                                     // assembling threads: the words of level 1, (level 2,) level 0
+    const bool last_thr = threadIdx.x < 2 * (HL_COLS + 2), asm_thr = threadIdx.x >= 128 && threadIdx.x < 128 + 2 * HL_COLS;
+    if (last_thr) {
         const int c = threadIdx.x >> 1, side = threadIdx.x & 1;
         const int x = x0 - 1 + c;
         const int j = WIN * b - 1 + side;
@@ -264,17 +259,31 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
             auto get = [&](int k, int dx, int dy) { return l1[c + 1 + dx][1 + side + dy][k]; };
             halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
         }
-        // own word -> line c-1; the one moving in +x is pulled by column x+1 (line c), the one moving in -x by column x-1 (line c-2)
-        const int q = NL - 1, base = 16 * side + 4 * q;
-        if (c >= 1 && c <= HL_COLS) { ol[c - 1][base] = side ? o[4] : o[2]; ol[c - 1][base + 3] = T(0); }
-        if (c < HL_COLS) ol[c][base + (side ? 2 : 1)] = side ? o[8] : o[5];
-        if (c >= 2) ol[c - 2][base + (side ? 1 : 2)] = side ? o[7] : o[6];
-    } else if (threadIdx.x >= 128 && threadIdx.x < 128 + 2 * HL_COLS) {
+        wl[0] = side ? o[4] : o[2]; wl[1] = side ? o[8] : o[5]; wl[2] = side ? o[7] : o[6];
+    } else if (asm_thr) {
         const int t = threadIdx.x - 128, o = t >> 1, side = t & 1;
-        halo_words_from<T>(ol, o, side, 0, l1, o + NL, NL - 1 + side);
-        if constexpr (DEPTH == 4) halo_words_from<T>(ol, o, side, 1, l2, o + NL - 1, NL - 2 + side);
+        auto words = [&](const auto &lk, int c, int r) {
+            return side == 0 ? t4{lk[c][r][2], lk[c - 1][r][5], lk[c + 1][r][6], T(0)} : t4{lk[c][r][4], lk[c + 1][r][7], lk[c - 1][r][8], T(0)};
+        };
+        wq[0] = words(l1, o + NL, NL - 1 + side);
+        if constexpr (DEPTH == 4) wq[1] = words(l2, o + NL - 1, NL - 2 + side);
+        wq[2] = *reinterpret_cast<const t4 *>(&lv0[o][side][0]);
     }
     H4_STAMP(4);
+    __syncthreads();
+    if (last_thr) {
+        // own word -> line c-1; the one moving in +x is pulled by column x+1 (line c), the one moving in -x by column x-1 (line c-2)
+        const int c = threadIdx.x >> 1, side = threadIdx.x & 1;
+        const int base = 16 * side + 4 * (NL - 1);
+        if (c >= 1 && c <= HL_COLS) { ol[c - 1][base] = wl[0]; ol[c - 1][base + 3] = T(0); }
+        if (c < HL_COLS) ol[c][base + (side ? 2 : 1)] = wl[1];
+        if (c >= 2) ol[c - 2][base + (side ? 1 : 2)] = wl[2];
+    } else if (asm_thr) {
+        const int t = threadIdx.x - 128, o = t >> 1, side = t & 1;
+        *reinterpret_cast<t4 *>(&ol[o][16 * side]) = wq[0];
+        if constexpr (DEPTH == 4) *reinterpret_cast<t4 *>(&ol[o][16 * side + 4]) = wq[1];
+        *reinterpret_cast<t4 *>(&ol[o][16 * side + 12]) = wq[2];
+    }
     __syncthreads();
     // ---- the block's lines: contiguous in memory
     {
