@@ -11,12 +11,12 @@
 // 196-225 VGPRs and T = 4 216-256 (two waves per SIMD either way; 16-byte vectors do not fit beyond T = 2).
 //
 // Pipeline of one wave (window w, columns [ia, ib)), iteration x (DEPTH = 3; DEPTH = 4: one more level, march_unit4):
-//     level 1 of column x      <- STEP_FS on the nine streamed vectors of column x        (march_step1, as in the two-step kernel)
+//     level 1 of column x      <- STEP_FS on the nine streamed vectors of column x        (march_align_in + march_step1)
 //     level 2 of column x - 1  <- STEP_FS on level 1 of columns x-2, x-1, x               (march_stage)
 //     level 3 of column x - 2  <- STEP_FS on level 2 of columns x-3, x-2, x-1 -> stored   (march_stage)
-// The rows just outside the window come from one halo table per level below the last (H1: level-1 values, H2, H3), built per
-// pass by k_halo3 / k_halo4 from the seam buffer S3 the previous pass wrote (four rows on either side of every seam) or, when
-// that is stale, from the lattice.
+// The rows just outside the window — of the lattice itself (level 0: the populations are loaded without a row shift) and of every
+// level below the last — come from the column's HALO LINE (below), built per pass by k_halo3 / k_halo4 from the seam buffer S3 the
+// previous pass wrote (four rows on either side of every seam) or, when that is stale, from the lattice.
 // Every site goes through the arithmetic of k_step DEPTH times: results are bit-identical to DEPTH single steps.
 #pragma once
 #include "step_march.hpp"
@@ -747,7 +747,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
 #undef LCOL
 }
 
-// The same machinery stopped after level 2: TWO steps per pass on the tables of the three-step plan (units, classes, H1, seam
+// The same machinery stopped after level 2: TWO steps per pass on the tables of the three-step plan (units, classes, halo lines, seam
 // buffer S3), for the one or two steps a step count leaves over after its three-step passes.
 template <bool BODY, bool EMIT, int FD, typename T, int S>
 __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Addr<T, S> &m, __amdgpu_buffer_rsrc_t rh, unsigned hoff, int ia, int ib,

@@ -135,7 +135,7 @@ struct wt_handle {
     int fuse_chunk_used = 0;
     uint8_t *bcode = nullptr;            // bounce codes, (nxl+2) * pitch
     uint8_t *wcls = nullptr;             // window-tile classes, nwin * (nxl+2)
-    void *halo_tab = nullptr;            // halo table of the marching kernels, (nwin+1) * (nxl+2) * 8 elements
+    void *halo_tab = nullptr;            // halo table of the two-step marching kernel, (nwin+1) * (nxl+2) * 8 elements (depth 3 / 4: hlines)
     void *seams = nullptr;               // seam rows written by a marching pass beside its output lattice, (nwin+1) * (nxl+2) * 48 elements
     uint8_t *seam_plain = nullptr;       // per (seam, column): both sites next to the seam are plain interior fluid, (nwin-1) * nxl
     bool seams_valid = false;            // `seams` describes lattice f[cur] (set by a marching pass, cleared by everything else that writes f)
@@ -1427,7 +1427,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
 // Steps the next fused pass advances given `left` steps to go (0: none — take a single step).  A pass needs as many exact ghost
 // columns as it advances steps.  The tables of a depth-D plan also run every shorter pass down to two steps, and a remainder of
 // ONE step is never left behind where two fused passes fit (5 = 3 + 2 on a four-step plan, 4 = 2 + 2 on a three-step plan): a
-// single k_step clears the seam buffer, and the next pass would then build its halo tables by the gather path.
+// single k_step clears the seam buffer, and the next pass would then build its halo lines by the gather path.
 static inline int fuse_pick(int depth, int avail)
 {
     if (avail < 2) return 0;

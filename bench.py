@@ -722,6 +722,12 @@ def main():
                                    if achieved is not None else "no counters: rocprofv3 unavailable (or --pmc-traffic 0) and no entry for this workload in profiles/pmc_traffic.json"),
                 "traffic": r["traffic"], "traffic_source": r["traffic_source"], "counter_gbps": r["counter_gbps"],
                 "compulsory_gbps": compulsory, "compulsory_frac": compulsory / HBM_PEAK_GBPS,
+                # counter bytes over the bytes every pass must move (read + write each population once): what re-reads, tables and fill columns add
+                "traffic_over_compulsory": (None if r["traffic"] is None or not launch_ms else r["traffic"] / (compulsory * 1e9 * launch_ms * 1e-3)),
+                "counter_calibration": ("FETCH_SIZE x 2 and WRITE_SIZE x 1 reproduce known byte counts in this kernel's own access shapes (16, 8, 4 bytes per lane; "
+                                        "tools/kfetchcal.hip, profiles/r04_u_fetch_calibration.txt)"),
+                "valu_busy_note": ("a per-wave activity count (it reads 0.85-0.92 on a kernel of nothing but packed FMAs at 2-4 waves per SIMD, "
+                                   "profiles/r04_x_issue_experiments.txt), not a pipe utilisation"),
                 "effective_gbps": r["effective_gbps"], "effective_frac": r["effective_frac"],
                 "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "launch_ms": launch_ms,
                 "steps_per_launch": steps_per_launch}
