@@ -98,8 +98,10 @@ __global__ __launch_bounds__(256) void k_seam_flags4(const uint8_t *__restrict__
 
 // STEP_FS (html:283-360), every branch in the reference's order, for site (x, j) on the previous level's values:
 // get(k, dx, dy) = population k of site (x + dx, j + dy) one level down
+// `sc` = the site's bounce code (bits 0..7: bit k-1 set <=> the site upstream of direction k is solid, k_bounce_codes) | 256 if the site itself is
+// solid — fetched by the caller at the start of the kernel, not behind a barrier
 template <typename T, int FD, typename GET>
-__device__ __forceinline__ void halo_step(const uint8_t *__restrict__ m, const Geom &g, int x, int j, bool plain, GET get, const FastDiv &fdv, T tau, T U0,
+__device__ __forceinline__ void halo_step(unsigned sc, const Geom &g, int x, int j, bool plain, GET get, const FastDiv &fdv, T tau, T U0,
                                           T (&o)[9])
 {
     if (j >= g.ny || x < 0 || x >= g.nxl) {
@@ -107,14 +109,13 @@ __device__ __forceinline__ void halo_step(const uint8_t *__restrict__ m, const G
         for (int k = 0; k < 9; k++) o[k] = T(0);
         return;
     }
-    const long c = (long)x * g.pitch + j;
     const int gi = x + g.gi0;
     if (plain) {                                                       // plain interior fluid: html:324-359 without the mask reads
         T fin[9], rho, ux, uy;
 #pragma unroll
         for (int k = 0; k < 9; k++) fin[k] = get(k, -ex_of(k), -ey_of(k));
         collide_t<T, FD>(fin, fdv, tau, o, rho, ux, uy);
-    } else if (m[c]) {                                                 // html:287-294 solid
+    } else if (sc & 256u) {                                            // html:287-294 solid
 #pragma unroll
         for (int k = 0; k < 9; k++) o[k] = get(opp_of(k), 0, 0);
     } else if (gi == g.nx_g - 1) {                                     // html:301-312 outlet
@@ -124,11 +125,9 @@ __device__ __forceinline__ void halo_step(const uint8_t *__restrict__ m, const G
         feq_all<T>(T(1), U0, T(0), o);
     } else {                                                           // html:324-359 interior fluid
         T fin[9], rho, ux, uy;
+        fin[0] = get(0, 0, 0);
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const long src = c - (long)ex_of(k) * g.pitch - ey_of(k);
-            fin[k] = m[src] ? get(opp_of(k), 0, 0) : get(k, -ex_of(k), -ey_of(k));
-        }
+        for (int k = 1; k < 9; k++) fin[k] = ((sc >> (k - 1)) & 1u) ? get(opp_of(k), 0, 0) : get(k, -ex_of(k), -ey_of(k));
         collide_t<T, FD>(fin, fdv, tau, o, rho, ux, uy);
     }
 }
@@ -140,9 +139,36 @@ __device__ unsigned long long g_halo_clk[8];      // diagnostic build: clocks of
 #define H4_STAMP(i) do { } while (0)
 #endif
 
+// site_step1 (step_march.hpp) for a site next to a seam whose inputs are all in the seam buffer: `a` = the nine pulled populations (already
+// fetched), `rec` = the record of column x, q0 = the site's row relative to row WIN b - 4.  A body / inlet / outlet site then costs nine more
+// dwords of records that are in the cache anyway instead of nine scattered lines of the lattice (a quarter of the halo kernel's HBM reads on the
+// bench lattice came from the few per cent of its sites that are not plain fluid).  Same branches, same order, same values (html:283-360).
+template <typename T, int FD>
+__device__ __forceinline__ void site_step1_seams(const T *__restrict__ rec, const T (&a)[9], int q0, unsigned sc, const Geom &g, int x, int j,
+                                                 const FastDiv &fdv, T tau, T U0, T (&out)[9])
+{
+    const int gi = x + g.gi0;
+    const int e0 = (q0 >> 2) * M3_SHALF + (q0 & 3);                // own-site element of direction k: e0 + 4 k
+    if (sc & 256u) {                                               // html:287-294 solid
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = rec[e0 + 4 * opp_of(k)];
+    } else if (gi == g.nx_g - 1) {                                 // html:301-312 outlet
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = rec[-M3_SREC + e0 + 4 * k];
+    } else if (gi == 0 || j == g.ny - 1 || j == 0) {               // html:314-322 far field
+        feq_all<T>(T(1), U0, T(0), out);
+    } else {                                                       // html:324-359 interior fluid
+        T fin[9], rho, ux, uy;
+        fin[0] = a[0];
+#pragma unroll
+        for (int k = 1; k < 9; k++) fin[k] = ((sc >> (k - 1)) & 1u) ? rec[e0 + 4 * opp_of(k)] : a[k];
+        collide_t<T, FD>(fin, fdv, tau, out, rho, ux, uy);
+    }
+}
+
 template <typename T, int S, int FD, int DEPTH>
 __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
-                                                const uint8_t *__restrict__ flags, T *__restrict__ hl, const Geom &g, int nwin, int use_seams,
+                                                const uint8_t *__restrict__ bcode, const uint8_t *__restrict__ flags, T *__restrict__ hl, const Geom &g, int nwin, int use_seams,
                                                 const FastDiv &fdv, T tau, T U0)
 {
     constexpr int WIN = 64 * S, NL = DEPTH - 1;
@@ -166,14 +192,25 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
 #endif
     // the plain-fluid flags of the columns this thread works on in the LATER phases are requested now, beside level 1's inputs: fetched where they
     // are used they put a trip to memory behind every barrier of a kernel that is a chain of latencies
-    unsigned fl2 = 0, fl3 = 0;
+    // ... and so are the solid flag and the bounce code of the thread's sites (`sc`, halo_step)
+    unsigned fl2 = 0, fl3 = 0, sc2 = 0, sc3 = 0;
+    auto site_code = [&](int x, int j) -> unsigned {
+        const long c = (long)x * g.pitch + j;
+        return (unsigned)bcode[c] | (m[c] ? 256u : 0u);
+    };
     if constexpr (DEPTH == 4) {
-        const int x = x0 - (NL - 1) + (int)threadIdx.x / R2;
-        if (x >= 0 && x < g.nxl) fl2 = flags[(long)(b - 1) * g.nxl + x];
+        const int x = x0 - (NL - 1) + (int)threadIdx.x / R2, j = WIN * b - (NL - 1) + (int)threadIdx.x % R2;
+        if (x >= 0 && x < g.nxl) {
+            fl2 = flags[(long)(b - 1) * g.nxl + x];
+            if (j < g.ny && !((fl2 >> ((int)threadIdx.x % R2 + 1)) & 1)) sc2 = site_code(x, j);       // (plain sites — nearly all — need none)
+        }
     }
     if (threadIdx.x < 2 * (HL_COLS + 2)) {
-        const int x = x0 - 1 + (int)(threadIdx.x >> 1);
-        if (x >= 0 && x < g.nxl) fl3 = flags[(long)(b - 1) * g.nxl + x];
+        const int x = x0 - 1 + (int)(threadIdx.x >> 1), j = WIN * b - 1 + (int)(threadIdx.x & 1);
+        if (x >= 0 && x < g.nxl) {
+            fl3 = flags[(long)(b - 1) * g.nxl + x];
+            if (j < g.ny && !((fl3 >> (NL - 1 + (int)(threadIdx.x & 1))) & 1)) sc3 = site_code(x, j);
+        }
     }
     // ---- level 1 (+ the lines' level-0 words)
     for (int w = threadIdx.x; w < C1 * R1; w += 256) {
@@ -210,6 +247,8 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
             if (plain) {
                 T rho, ux, uy;
                 collide_t<T, FD>(a, fdv, tau, o, rho, ux, uy);
+            } else if (use_seams) {
+                site_step1_seams<T, FD>(rec, a, 4 - NL + r, site_code(x, j), g, x, j, fdv, tau, U0, o);
             } else {
                 site_step1<T, FD>(s, m, g, x, j, fdv, tau, U0, o);
             }
@@ -233,7 +272,7 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
             const bool plain = ((fl2 >> (r + 1)) & 1) != 0;              // (C2 R2 = 256: this thread's one item is the column fl2 was fetched for)
             auto get = [&](int k, int dx, int dy) { return l1[c2 + 1 + dx][r + 1 + dy][k]; };
             T o[9];
-            halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
+            halo_step<T, FD>(sc2, g, x, j, plain, get, fdv, tau, U0, o);
 #pragma unroll
             for (int k = 0; k < 9; k++) l2[c2][r][k] = o[k];
         }
@@ -254,10 +293,10 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
         T o[9];
         if constexpr (DEPTH == 4) {
             auto get = [&](int k, int dx, int dy) { return l2[c + 1 + dx][1 + side + dy][k]; };
-            halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
+            halo_step<T, FD>(sc3, g, x, j, plain, get, fdv, tau, U0, o);
         } else {
             auto get = [&](int k, int dx, int dy) { return l1[c + 1 + dx][1 + side + dy][k]; };
-            halo_step<T, FD>(m, g, x, j, plain, get, fdv, tau, U0, o);
+            halo_step<T, FD>(sc3, g, x, j, plain, get, fdv, tau, U0, o);
         }
         wl[0] = side ? o[4] : o[2]; wl[1] = side ? o[8] : o[5]; wl[2] = side ? o[7] : o[6];
     } else if (asm_thr) {
@@ -303,15 +342,17 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
 
 template <typename T, int S, int FD>
 __global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
-                                               const uint8_t *__restrict__ flags3, T *__restrict__ hl, Geom g, int nwin, int use_seams, FastDiv fdv, T tau, T U0)
+                                               const uint8_t *__restrict__ bcode, const uint8_t *__restrict__ flags3, T *__restrict__ hl, Geom g, int nwin, int use_seams,
+                                               FastDiv fdv, T tau, T U0)
 {
-    halo_lines_body<T, S, FD, 3>(fs, seams3, mask, flags3, hl, g, nwin, use_seams, fdv, tau, U0);
+    halo_lines_body<T, S, FD, 3>(fs, seams3, mask, bcode, flags3, hl, g, nwin, use_seams, fdv, tau, U0);
 }
 template <typename T, int S, int FD>
 __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
-                                               const uint8_t *__restrict__ flags4, T *__restrict__ hl, Geom g, int nwin, int use_seams, FastDiv fdv, T tau, T U0)
+                                               const uint8_t *__restrict__ bcode, const uint8_t *__restrict__ flags4, T *__restrict__ hl, Geom g, int nwin, int use_seams,
+                                               FastDiv fdv, T tau, T U0)
 {
-    halo_lines_body<T, S, FD, 4>(fs, seams3, mask, flags4, hl, g, nwin, use_seams, fdv, tau, U0);
+    halo_lines_body<T, S, FD, 4>(fs, seams3, mask, bcode, flags4, hl, g, nwin, use_seams, fdv, tau, U0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1374,12 +1374,12 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
         if (h->march_depth == 4) {      // the plan's tables are those of the four-step pass, whatever this pass advances
             const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H4_COLS - 1) / H4_COLS);
-            hipLaunchKernelGGL((k_halo4<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
+            hipLaunchKernelGGL((k_halo4<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->bcode, (const uint8_t *)h->seam_plain,
                                reinterpret_cast<T *>(h->hlines), g, h->n_win,
                                h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
         } else {
             const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H3_COLS - 1) / H3_COLS);
-            hipLaunchKernelGGL((k_halo3<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->seam_plain,
+            hipLaunchKernelGGL((k_halo3<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->bcode, (const uint8_t *)h->seam_plain,
                                reinterpret_cast<T *>(h->hlines), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
         }
     }
