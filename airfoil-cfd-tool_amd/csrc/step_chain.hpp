@@ -86,26 +86,25 @@ template <> struct ChainPops<-1> { static constexpr int B0 = 3, B1 = 6, B2 = 7, 
 // one more application of STEP_FS in registers (plain interior fluid): level k+1 of column c from level k of the column behind
 // (`mb`: its three populations moving forward), of column c itself (`Gc`) and of the column ahead (`ma`: three populations moving
 // backward); `hv`, `lb` = column c's halo line and the level's first lane (as in march_stage)
-template <int DIR, bool WANT_MACRO, int FD, typename T, int S>
+template <int DIR, bool WANT_MACRO, int FD, int LB, typename T, int S>
 __device__ __forceinline__ void chain_stage(const MarchParams<T> &p, int j0, int lane, bool far_win, const T (&feq0)[9], const MV<T, S> (&mb)[3],
-                                            const MV<T, S> (&Gc)[9], const MV<T, S> (&ma)[3], T hv, int lb, MV<T, S> (&out)[9], MV<T, S> (&mac)[3])
+                                            const MV<T, S> (&Gc)[9], const MV<T, S> (&ma)[3], T hv, MV<T, S> (&out)[9], MV<T, S> (&mac)[3])
 {
     typedef MV<T, S> V3;
     typedef ChainPops<DIR> P;
-    const T hb2 = readlane_t(hv, lb), hb5 = readlane_t(hv, lb + 1), hb6 = readlane_t(hv, lb + 2), ha4 = readlane_t(hv, lb + 16), ha7 = readlane_t(hv, lb + 17),
-            ha8 = readlane_t(hv, lb + 18);
-    // halo value of population k's row outside the window (5, 6 from below; 7, 8 from above)
-    auto edge = [&](int k) { return k == 5 ? hb5 : (k == 6 ? hb6 : (k == 7 ? ha7 : ha8)); };
+    // the word of population k's row outside the window: slot 0 = 2 / 4 (own column), 1 = 5 / 7, 2 = 6 / 8 (step_march3.hpp, halo lines)
+    constexpr int SB1 = P::B1 == 5 ? 1 : 2, SA1 = P::A1 == 5 ? 1 : 2;          // from below: populations 5, 6
+    constexpr int SB2 = P::B2 == 7 ? 1 : 2, SA2 = P::A2 == 7 ? 1 : 2;          // from above: populations 7, 8
     V3 fin[9];
     fin[0] = Gc[0];
-    fin[2] = m_below(Gc[2], lane, hb2);
-    fin[4] = m_above(Gc[4], lane, ha4);
+    fin[2] = m_below_h<LB>(Gc[2], hv);
+    fin[4] = m_above_h<LB>(Gc[4], hv);
     fin[P::B0] = mb[0];
-    fin[P::B1] = m_below(mb[1], lane, edge(P::B1));
-    fin[P::B2] = m_above(mb[2], lane, edge(P::B2));
+    fin[P::B1] = m_below_h<LB + SB1>(mb[1], hv);
+    fin[P::B2] = m_above_h<LB + SB2>(mb[2], hv);
     fin[P::A0] = ma[0];
-    fin[P::A1] = m_below(ma[1], lane, edge(P::A1));
-    fin[P::A2] = m_above(ma[2], lane, edge(P::A2));
+    fin[P::A1] = m_below_h<LB + SA1>(ma[1], hv);
+    fin[P::A2] = m_above_h<LB + SA2>(ma[2], hv);
     march_collide<T, S, FD, WANT_MACRO>(fin, p.fdv, p.tau, out, mac);
     if (far_win) march_far_rows<T, S, WANT_MACRO>(j0, p.g.ny, p.U0, feq0, out, mac);
 }
@@ -146,6 +145,21 @@ struct ChainUnit {
     //   PS: publish this unit's level-PS triple for the start-seam partner, right after stage PS;
     //   RE: take the end-seam partner's level-RE triple as the column ahead of stage RE + 1, the first stage of this (drain) iteration;
     //   PE: publish this unit's level-PE triple for the end-seam partner, right after stage PE.
+    // stage K of an iteration (see iter): level K of column x - (K-1) DIR
+    template <int K, int MASK, int RS, int PS, int RE, int PE>
+    __device__ __forceinline__ void stage_k(V3 (&G)[DEPTH + 1][9], V3 (&mac)[3])
+    {
+        if constexpr (K <= DEPTH && ((MASK >> (K - 1)) & 1) != 0) {
+            V3 ma[3];
+            if constexpr (((MASK >> (K - 2)) & 1) != 0) { ma[0] = G[K - 1][P::A0]; ma[1] = G[K - 1][P::A1]; ma[2] = G[K - 1][P::A2]; }
+            else chain_receive(lds.x[1][K - 2][pos ^ 3], lds.flag[1][K - 2][pos ^ 3], lane, ma, p.stuck);           // RE == K - 1 (positions 1 <-> 2)
+            if constexpr (RS == K - 1) chain_receive(lds.x[0][K - 2][pos ^ 1], lds.flag[0][K - 2][pos ^ 1], lane, sm[K - 2], p.stuck);
+            chain_stage<DIR, (K == DEPTH) && EMIT, FD, 4 * (K - 2)>(p, j0, lane, far_win, feq0, sm[K - 2], sc[K - 2], ma, hv[K - 1], G[K], mac);
+            if constexpr (K < DEPTH && PS == K) chain_publish(lds.x[0][K - 1][pos], lds.flag[0][K - 1][pos], lane, G[K][P::A0], G[K][P::A1], G[K][P::A2]);
+            if constexpr (K < DEPTH && PE == K) chain_publish(lds.x[1][K - 1][pos], lds.flag[1][K - 1][pos], lane, G[K][P::B0], G[K][P::B1], G[K][P::B2]);
+        }
+    }
+
     template <int MASK, int RS, int PS, int RE, int PE>
     __device__ __forceinline__ void iter(int x)
     {
@@ -163,18 +177,9 @@ struct ChainUnit {
             if (PS == 1) chain_publish(lds.x[0][0][pos], lds.flag[0][0][pos], lane, G[1][P::A0], G[1][P::A1], G[1][P::A2]);
             if (PE == 1) chain_publish(lds.x[1][0][pos], lds.flag[1][0][pos], lane, G[1][P::B0], G[1][P::B1], G[1][P::B2]);
         }
-#pragma unroll
-        for (int k = 2; k <= DEPTH; k++) {
-            if (!((MASK >> (k - 1)) & 1)) continue;
-            V3 ma[3];
-            if ((MASK >> (k - 2)) & 1) { ma[0] = G[k - 1][P::A0]; ma[1] = G[k - 1][P::A1]; ma[2] = G[k - 1][P::A2]; }
-            else chain_receive(lds.x[1][k - 2][pos ^ 3], lds.flag[1][k - 2][pos ^ 3], lane, ma, p.stuck);           // RE == k - 1 (positions 1 <-> 2)
-            if (RS == k - 1) chain_receive(lds.x[0][k - 2][pos ^ 1], lds.flag[0][k - 2][pos ^ 1], lane, sm[k - 2], p.stuck);
-            if (k == DEPTH) chain_stage<DIR, EMIT, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 1], 4 * (k - 2), G[k], mac);
-            else chain_stage<DIR, false, FD>(p, j0, lane, far_win, feq0, sm[k - 2], sc[k - 2], ma, hv[k - 1], 4 * (k - 2), G[k], mac);
-            if (k < DEPTH && PS == k) chain_publish(lds.x[0][k - 1][pos], lds.flag[0][k - 1][pos], lane, G[k][P::A0], G[k][P::A1], G[k][P::A2]);
-            if (k < DEPTH && PE == k) chain_publish(lds.x[1][k - 1][pos], lds.flag[1][k - 1][pos], lane, G[k][P::B0], G[k][P::B1], G[k][P::B2]);
-        }
+        stage_k<2, MASK, RS, PS, RE, PE>(G, mac);
+        stage_k<3, MASK, RS, PS, RE, PE>(G, mac);
+        stage_k<4, MASK, RS, PS, RE, PE>(G, mac);
         static_assert(RE == 0 || (((MASK >> RE) & 1) && !((MASK >> (RE - 1)) & 1)), "RE names the level below the first stage of a drain iteration");
         if (LAST) {
             pin_after(G[DEPTH]);
@@ -299,10 +304,11 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
     a.lane = lane;
     // halo lines (step_march3.hpp): lanes 0..15 hold the first half of the line of (seam w, column c) — window w's words from below, levels 1, 2, 3, 0 in
-    // four lanes each —, lanes 16..31 the second half of the line of (seam w+1, column c): its words from above
+    // four lanes each —, lanes 48..63 the second half of the line of (seam w+1, column c): its words from above (row 0 / row 3 of the wave: the stages
+    // fetch them with row shifts, m_below_h / m_above_h)
     const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * (unsigned)M3_HL * EB;
     const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.hlines, hbytes);
-    const unsigned hoff = (unsigned)(((w + (lane >= 16 && lane < M3_HL ? 1 : 0)) * (g.nxl + 2) + 1) * M3_HL + (lane < M3_HL ? lane : 0)) * EB;
+    const unsigned hoff = (unsigned)(lane >= 48 ? ((w + 1) * (g.nxl + 2) + 1) * M3_HL + lane - 32 : (w * (g.nxl + 2) + 1) * M3_HL + (lane < 16 ? lane : 0)) * EB;
     {
         // per wave, in elements: below[40] (slot k = the window's last four rows of direction k, staged by the last 4/S lanes; slot
         // 9 stays zero), above[40] (rows 0..3, the first 4/S lanes), then a scratch area for the other lanes' writes

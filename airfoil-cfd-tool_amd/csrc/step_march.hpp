@@ -344,6 +344,51 @@ template <typename T, int S> __device__ __forceinline__ MV<T, S> m_above(const M
     return o;
 }
 
+// The same with the row outside the window taken straight out of the column's halo register `hv` (step_march3.hpp: lanes 0..15 hold the words that
+// come from below, lanes 48..63 those from above) by a ROW shift — lane N into lane 0 (resp. lane 48 + P into lane 63) — and the wave shift then leaving
+// that lane alone: two data-parallel-primitive moves per direction instead of a v_readlane, a move and a select (the kernel is bound by the number of
+// vector instructions it issues, and the six wave-uniform edge values of every stage no longer pass through scalar registers).
+template <int N> __device__ __forceinline__ int dpp_shift_below(int x, int hv)
+{
+    static_assert(N >= 0 && N < 16, "from-below words live in lanes 0..15");
+    int e = hv;
+    if constexpr (N > 0) e = __builtin_amdgcn_update_dpp(hv, hv, 0x100 + N, 0x1, 0xf, false);        // row_shl:N, row 0 only: lane 0 <- lane N
+    return __builtin_amdgcn_update_dpp(e, x, 0x138, 0xf, 0xf, false);                                   // wave_shr:1: lane i <- lane i-1, lane 0 keeps e
+}
+template <int P> __device__ __forceinline__ int dpp_shift_above(int x, int hv)
+{
+    static_assert(P >= 0 && P < 16, "from-above words live in lanes 48..63");
+    int e = hv;
+    if constexpr (P < 15) e = __builtin_amdgcn_update_dpp(hv, hv, 0x110 + (15 - P), 0x8, 0xf, false);   // row_shr:15-P, row 3 only: lane 63 <- lane 48+P
+    return __builtin_amdgcn_update_dpp(e, x, 0x130, 0xf, 0xf, false);                                   // wave_shl:1: lane i <- lane i+1, lane 63 keeps e
+}
+template <int N> __device__ __forceinline__ float shift_below_h(float x, float hv) { return __int_as_float(dpp_shift_below<N>(__float_as_int(x), __float_as_int(hv))); }
+template <int N> __device__ __forceinline__ double shift_below_h(double x, double hv)
+{
+    return __hiloint2double(dpp_shift_below<N>(__double2hiint(x), __double2hiint(hv)), dpp_shift_below<N>(__double2loint(x), __double2loint(hv)));
+}
+template <int P> __device__ __forceinline__ float shift_above_h(float x, float hv) { return __int_as_float(dpp_shift_above<P>(__float_as_int(x), __float_as_int(hv))); }
+template <int P> __device__ __forceinline__ double shift_above_h(double x, double hv)
+{
+    return __hiloint2double(dpp_shift_above<P>(__double2hiint(x), __double2hiint(hv)), dpp_shift_above<P>(__double2loint(x), __double2loint(hv)));
+}
+template <int N, typename T, int S> __device__ __forceinline__ MV<T, S> m_below_h(const MV<T, S> &r, T hv)
+{
+    MV<T, S> o;
+    o.v[0] = shift_below_h<N>(r.v[S - 1], hv);
+#pragma unroll
+    for (int v = 1; v < S; v++) o.v[v] = r.v[v - 1];
+    return o;
+}
+template <int P, typename T, int S> __device__ __forceinline__ MV<T, S> m_above_h(const MV<T, S> &r, T hv)
+{
+    MV<T, S> o;
+#pragma unroll
+    for (int v = 0; v < S - 1; v++) o.v[v] = r.v[v + 1];
+    o.v[S - 1] = shift_above_h<P>(r.v[0], hv);
+    return o;
+}
+
 // buffer addressing: rsrc = whole lattice; voff = the lane's byte offset (j0 * sizeof(T), loop-invariant);
 // soff = scalar byte offset of (plane, column, row shift)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t march_rsrc(const void *p, unsigned bytes)
@@ -490,11 +535,41 @@ __device__ __forceinline__ SiteBytes site_bytes_load(const MarchParams<T> &p, in
 // is bound by its instruction stream, and loses 1-1.5 % in the three-step kernel on slab-sized lattices.
 static constexpr int MARCH_FD_PACKED = 4;
 typedef float f2v __attribute__((ext_vector_type(2)));
+// a / b for two sites at once, operation for operation hipcc's own expansion of the IEEE binary32 division (LLVM AMDGPUTargetLowering::LowerFDIV32 with
+// fp32 denormals on: v_div_scale x2, v_rcp, fma, fma, mul, fma, fma, fma, v_div_fmas, v_div_fixup) — the same instructions on the same values, so the same
+// bits — with the six multiply-adds in between as PACKED instructions over the two sites: the marching kernel is bound by the number of vector
+// instructions it issues (an un-packed collision costs it 20 %), and the two divisions per site were a sixth of them.
+__device__ __forceinline__ f2v div2_ieee(f2v a, f2v b)
+{
+    bool s0, s1, dummy;
+    const f2v ds = {__builtin_amdgcn_div_scalef(a[0], b[0], false, &dummy), __builtin_amdgcn_div_scalef(a[1], b[1], false, &dummy)};     // denominator scaled
+    const f2v ns = {__builtin_amdgcn_div_scalef(a[0], b[0], true, &s0), __builtin_amdgcn_div_scalef(a[1], b[1], true, &s1)};             // numerator scaled
+    const f2v rc = {__builtin_amdgcn_rcpf(ds[0]), __builtin_amdgcn_rcpf(ds[1])};
+    const f2v one = {1.0f, 1.0f};
+    const f2v f0 = __builtin_elementwise_fma(-ds, rc, one);
+    const f2v f1 = __builtin_elementwise_fma(f0, rc, rc);
+    const f2v mu = ns * f1;
+    const f2v f2 = __builtin_elementwise_fma(-ds, mu, ns);
+    const f2v f3 = __builtin_elementwise_fma(f2, f1, mu);
+    const f2v f4 = __builtin_elementwise_fma(-ds, f3, ns);
+    f2v q;
+    q[0] = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(f4[0], f1[0], f3[0], s0), b[0], a[0]);
+    q[1] = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(f4[1], f1[1], f3[1], s1), b[1], a[1]);
+    return q;
+}
+
 template <int FD>
 __device__ __forceinline__ void collide2_packed(const f2v (&fin)[9], const FastDiv &fdv, f2v (&fo)[9], f2v &rho, f2v &ux, f2v &uy)
 {
     f2v r, u, v;
-    moments<f2v>(fin, r, u, v);
+    {   // moments (d2q9.hpp, html:335-338) with the two divisions packed
+        f2v rs = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 9; k++) rs += fin[k];
+        r = rs;
+        u = div2_ieee(fin[1] + fin[5] + fin[8] - fin[3] - fin[6] - fin[7], rs);
+        v = div2_ieee(fin[2] + fin[5] + fin[6] - fin[4] - fin[7] - fin[8], rs);
+    }
     const float rhoMin = 0.5f, rhoMax = 2.0f, uMax = 0.35f;        // html:344
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -773,14 +848,12 @@ template <typename T> __device__ __forceinline__ T halo_load(__amdgpu_buffer_rsr
 }
 
 // march_load_aligned's inputs of one column -> the streamed (pulled) inputs: populations 2,5,6 come from one row below, 4,7,8 from one row above;
-// `hv` = the column's halo words, level 0 in lanes 12..14 (from below) and 28..30 (from above)
+// `hv` = the column's halo words, level 0 in lanes 12..14 (from below) and 60..62 (from above)
 template <typename T, int S>
 __device__ __forceinline__ void march_align_in(MV<T, S> (&in)[9], int lane, T hv)
 {
-    const T hb2 = readlane_t(hv, 12), hb5 = readlane_t(hv, 13), hb6 = readlane_t(hv, 14), ha4 = readlane_t(hv, 28), ha7 = readlane_t(hv, 29),
-            ha8 = readlane_t(hv, 30);
-    in[2] = m_below(in[2], lane, hb2); in[5] = m_below(in[5], lane, hb5); in[6] = m_below(in[6], lane, hb6);
-    in[4] = m_above(in[4], lane, ha4); in[7] = m_above(in[7], lane, ha7); in[8] = m_above(in[8], lane, ha8);
+    in[2] = m_below_h<12>(in[2], hv); in[5] = m_below_h<13>(in[5], hv); in[6] = m_below_h<14>(in[6], hv);
+    in[4] = m_above_h<12>(in[4], hv); in[7] = m_above_h<13>(in[7], hv); in[8] = m_above_h<14>(in[8], hv);
 }
 
 // Step 1 of column x -> G (all nine directions).  `in` holds the streamed inputs of column x (modified in place).

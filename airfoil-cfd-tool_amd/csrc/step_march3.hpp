@@ -377,20 +377,18 @@ struct March3Addr {
 
 // one more application of STEP_FS in registers: level k+1 of column c from level k of columns c-1 (populations 1,5,8: m158),
 // c (all nine: Gc) and c+1 (3,6,7 of Gn); `hv`, `lb`: this column's halo line (lanes 0..23) and the level's first lane
-template <bool BODY, bool WANT_MACRO, int FD, typename T, int S>
+template <bool BODY, bool WANT_MACRO, int FD, int LB, typename T, int S>
 __device__ __forceinline__ void march_stage(const MarchParams<T> &p, int c, int j0, int lane, bool far_win, bool nf, bool allsolid,
-                                            const T (&feq0)[9], const MV<T, S> (&m158)[3], const MV<T, S> (&Gc)[9], const MV<T, S> (&Gn)[9], T hv, int lb,
+                                            const T (&feq0)[9], const MV<T, S> (&m158)[3], const MV<T, S> (&Gc)[9], const MV<T, S> (&Gn)[9], T hv,
                                             MV<T, S> (&out)[9], MV<T, S> (&mac)[3], const uint32_t *pre = nullptr)
 {
     typedef MV<T, S> V3;
     const Geom &g = p.g;
-    // `hv` = this lane's element of column c's halo words, `lb` = 4 (level - 1): the lane of the level's first from-below word (from above: + 16)
-    const T hb2 = readlane_t(hv, lb), hb5 = readlane_t(hv, lb + 1), hb6 = readlane_t(hv, lb + 2), ha4 = readlane_t(hv, lb + 16), ha7 = readlane_t(hv, lb + 17),
-                ha8 = readlane_t(hv, lb + 18);
+    // `hv` = this lane's element of column c's halo words, LB = 4 (level - 1): the lane of the level's first from-below word (from above: 48 + LB)
     V3 fin[9];
     fin[0] = Gc[0]; fin[1] = m158[0]; fin[3] = Gn[3];
-    fin[2] = m_below(Gc[2], lane, hb2); fin[5] = m_below(m158[1], lane, hb5); fin[6] = m_below(Gn[6], lane, hb6);
-    fin[4] = m_above(Gc[4], lane, ha4); fin[8] = m_above(m158[2], lane, ha8); fin[7] = m_above(Gn[7], lane, ha7);
+    fin[2] = m_below_h<LB>(Gc[2], hv); fin[5] = m_below_h<LB + 1>(m158[1], hv); fin[6] = m_below_h<LB + 2>(Gn[6], hv);
+    fin[4] = m_above_h<LB>(Gc[4], hv); fin[8] = m_above_h<LB + 2>(m158[2], hv); fin[7] = m_above_h<LB + 1>(Gn[7], hv);
     if (BODY) {
         const int gi = c + g.gi0;
         if (__builtin_expect(gi <= 0 || nf, 0)) {
@@ -578,13 +576,13 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         STEP1P(x, in, G1, sb0);                                                // level 1 of column x
         M3_STAMP(1);
         // level 2 of column x-1 (a column left of the inlet takes the inlet branch: constants, no memory access)
-        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, 0, G2, mac, BODY ? sb1.v : nullptr);
+        march_stage<BODY, false, FD, 0>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);
 #ifdef WT_M3_STAMPS
         pin_after(G2);
 #endif
         M3_STAMP(2);
         V3 out[9];
-        march_stage<BODY, EMIT, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, 4, out, mac, BODY ? sb2.v : nullptr);
+        march_stage<BODY, EMIT, FD, 4>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, out, mac, BODY ? sb2.v : nullptr);
         pin_after(out);
         M3_STAMP(3);
         wait_for_column(nxt, hvn);
@@ -628,7 +626,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         t2m[0] = s2c[1]; t2m[1] = s2c[5]; t2m[2] = s2c[8];
         const T hv2t = halo_load<T>(rh, hoff, (unsigned)(co - 1) * HREC);
         Seam3 sp = seam3_fetch(m);
-        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2t, 4, out, mac);
+        march_stage<BODY, EMIT, FD, 4>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2t, out, mac);
         march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = co - 1;
@@ -716,10 +714,10 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         const Seam3 sp = seam3_fetch(m);
         march_align_in(in, lane, hv0);
         march_step1<BODY, FD, T, S>(p, a, x, j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G1, BODY ? sb0.v : nullptr);      // level 1 of column x
-        march_stage<BODY, false, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, 0, G2, mac, BODY ? sb1.v : nullptr);     // level 2 of x-1
-        march_stage<BODY, false, FD>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, 4, G3, mac, BODY ? sb2.v : nullptr);     // level 3 of x-2
+        march_stage<BODY, false, FD, 0>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);     // level 2 of x-1
+        march_stage<BODY, false, FD, 4>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, G3, mac, BODY ? sb2.v : nullptr);     // level 3 of x-2
         V3 out[9];
-        march_stage<BODY, EMIT, FD>(p, c3, j0, lane, far_win, NONFAST(c3), ALLSOLID(c3), feq0, s3m, s3c, G3, hv3, 8, out, mac, BODY ? sb3.v : nullptr);     // level 4 of x-3
+        march_stage<BODY, EMIT, FD, 8>(p, c3, j0, lane, far_win, NONFAST(c3), ALLSOLID(c3), feq0, s3m, s3c, G3, hv3, out, mac, BODY ? sb3.v : nullptr);     // level 4 of x-3
         pin_after(out);
         wait_for_column(nxt, hvn);
         if (BODY) { wait_for_bytes(sbn); sb3 = sb2; sb2 = sb1; sb1 = sb0; sb0 = sbn; }
@@ -749,7 +747,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         if (any_solid) { auto own = [&](int k) { return G1[k]; }; march_solid<T, S, false>(O2, mac, solid4, own); }
         // level 3 of co-1
         tm[0] = s2c[1]; tm[1] = s2c[5]; tm[2] = s2c[8];
-        march_stage<BODY, false, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, G2, O2, halo_load<T>(rh, hoff, HCOL(co - 1)), 4, L3a, mac);
+        march_stage<BODY, false, FD, 4>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, G2, O2, halo_load<T>(rh, hoff, HCOL(co - 1)), L3a, mac);
         // level 3 of co
 #pragma unroll
         for (int k = 0; k < 9; k++) O3[k] = G2[k];
@@ -759,14 +757,14 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         Seam3 sp = seam3_fetch(m);
         // (a last unit of a single marched column does not own column co-2, and its level 3 of co-3 is not valid: drop the stores)
         const bool own2 = co - 2 >= ia;
-        march_stage<BODY, EMIT, FD>(p, co - 2, j0, lane, far_win, NONFAST(co - 2), ALLSOLID(co - 2), feq0, tm, G3, L3a, halo_load<T>(rh, hoff, HCOL(co - 2)), 8, out, mac);
+        march_stage<BODY, EMIT, FD, 8>(p, co - 2, j0, lane, far_win, NONFAST(co - 2), ALLSOLID(co - 2), feq0, tm, G3, L3a, halo_load<T>(rh, hoff, HCOL(co - 2)), out, mac);
         march3_store<EMIT>(m, own2 ? a.voff_st : p.lat_bytes, own2 ? co - 2 : 0, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = own2 ? co - 2 : seam_col;
         // level 4 of co-1
         tm[0] = G3[1]; tm[1] = G3[5]; tm[2] = G3[8];
         sp = seam3_fetch(m);
-        march_stage<BODY, EMIT, FD>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, L3a, O3, halo_load<T>(rh, hoff, HCOL(co - 1)), 8, out, mac);
+        march_stage<BODY, EMIT, FD, 8>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, L3a, O3, halo_load<T>(rh, hoff, HCOL(co - 1)), out, mac);
         march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
         seam3_flush(m, seam_col, sp);
         seam_col = co - 1;
@@ -829,7 +827,7 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Ad
         march_align_in(in, lane, hv0);
         STEP1(x, in, G1);
         V3 out[9];
-        march_stage<BODY, EMIT, FD>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, 0, out, mac);
+        march_stage<BODY, EMIT, FD, 0>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, out, mac);
         pin_after(out);
         wait_for_column(nxt, hvn);
         hv1 = hv0; hv0 = hvn;
