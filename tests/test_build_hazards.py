@@ -41,10 +41,6 @@ def test_no_step_kernel_uses_scratch(isa_files):
                 continue
             seen += 1
             limit = 48 if "k_halo" in name else 0
-            # the opt-in contracted-arithmetic instantiation (FD = 8: `fast_math`, never the default) that also emits the macroscopic fields — one
-            # launch per stepping call — may keep one loop-invariant constant of its general (body) loop there: 12 bytes since the halo lines
-            if "k_march3" in name and "Lb1ELi8E" in name:
-                limit = 16
             if r.get("private_seg_size", 0) > limit:
                 spilling.append((name, r))
     assert seen >= 30, seen
