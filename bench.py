@@ -316,8 +316,11 @@ def select_valu(per_kernel, fused, depth, n_simd, launch_ms):
     if clocks > 0:
         out["valu_busy_frac"] = tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (n_simd * clocks)
         out["effective_clock_ghz"] = clocks / (launch_ms * 1e-3) / 1e9      # profiled clocks over the UN-profiled launch time: indicative only
-    else:
+    # GRBM_GUI_ACTIVE has been seen ten times too large on a launch of a millisecond (configs[3]: "22 GHz"): a clock outside what the part
+    # can run at means the counter pass is not to be trusted — fall back to the nominal clock and say so
+    if not (clocks > 0 and 1.0 <= out["effective_clock_ghz"] <= 3.0):
         out["valu_busy_frac"] = out["valu_busy_frac_at_2p4_ghz"]
+        out["clock_note"] = "GRBM_GUI_ACTIVE implausible for this launch time: valu_busy_frac taken at the nominal 2.4 GHz"
     return out
 
 
