@@ -10,7 +10,9 @@ HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -fvisi
 ifeq ($(EXPERIMENT),1)
 HIPFLAGS += -DWT_EXPERIMENT_KNOBS
 endif
-LDFLAGS  ?= -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -Wl,--version-script=$(CSRC)/libwindtunnel.map
+# No -lrccl: the RCCL entry points are bound at the first wt_comm_* call to the ONE RCCL the process has mapped (csrc/rccl_bind.hpp); the run path is
+# for processes without PyTorch, where that call has to dlopen librccl.so.1 itself.
+LDFLAGS  ?= -ldl -Wl,-rpath,/opt/rocm/lib -Wl,--version-script=$(CSRC)/libwindtunnel.map
 
 all: lib oracle
 

@@ -68,11 +68,13 @@ static inline int march_nwin(int ny, int win) { return (ny + win - 1) / win; }
 
 // collision for either element type: fp32 with the division selected by FD (d2q9.hpp), fp64 always IEEE
 static constexpr int MARCH_FD_CONTRACTED = 8;    // bit 3 of FD: the opt-in contracted collision (d2q9.hpp collide_contracted; fp32 only)
+static constexpr int MARCH_FD_TWOOP = 16;        // bit 4 of FD: the two-operation division by tau (d2q9.hpp; fp32, proved per tau like the three-operation one)
 template <typename T, int FD>
 __device__ __forceinline__ void collide_t(const T (&fin)[9], const FastDiv &fdv, T tau, T (&fo)[9], T &rho, T &ux, T &uy)
 {
     if constexpr (sizeof(T) == 4 && (FD & MARCH_FD_CONTRACTED) != 0) collide_contracted(fin, fdv.rtau, fo, rho, ux, uy);
-    else if constexpr (sizeof(T) == 4) collide_fd<(FD & 3)>(fin, fdv, fo, rho, ux, uy);
+    else if constexpr (sizeof(T) == 4) collide_fd<(FD & 3), (FD & MARCH_FD_TWOOP) != 0>(fin, fdv, fo, rho, ux, uy);
+    else if constexpr ((FD & 3) != 0) collide_fd64(fin, fdv, fo, rho, ux, uy);       // fp64: the four-operation division, guarded (d2q9.hpp)
     else collide<T>(fin, tau, fo, rho, ux, uy);
 }
 
@@ -351,15 +353,16 @@ template <typename T, int S> __device__ __forceinline__ MV<T, S> m_above(const M
 template <int N> __device__ __forceinline__ int dpp_shift_below(int x, int hv)
 {
     static_assert(N >= 0 && N < 16, "from-below words live in lanes 0..15");
+    // (mov_dpp: the lanes the row shift does not write are don't-care — only lane 0 of `e` is used —, so the move needs no copy of hv in its destination first)
     int e = hv;
-    if constexpr (N > 0) e = __builtin_amdgcn_update_dpp(hv, hv, 0x100 + N, 0x1, 0xf, false);        // row_shl:N, row 0 only: lane 0 <- lane N
+    if constexpr (N > 0) e = __builtin_amdgcn_mov_dpp(hv, 0x100 + N, 0x1, 0xf, false);               // row_shl:N, row 0 only: lane 0 <- lane N
     return __builtin_amdgcn_update_dpp(e, x, 0x138, 0xf, 0xf, false);                                   // wave_shr:1: lane i <- lane i-1, lane 0 keeps e
 }
 template <int P> __device__ __forceinline__ int dpp_shift_above(int x, int hv)
 {
     static_assert(P >= 0 && P < 16, "from-above words live in lanes 48..63");
     int e = hv;
-    if constexpr (P < 15) e = __builtin_amdgcn_update_dpp(hv, hv, 0x110 + (15 - P), 0x8, 0xf, false);   // row_shr:15-P, row 3 only: lane 63 <- lane 48+P
+    if constexpr (P < 15) e = __builtin_amdgcn_mov_dpp(hv, 0x110 + (15 - P), 0x8, 0xf, false);          // row_shr:15-P, row 3 only: lane 63 <- lane 48+P
     return __builtin_amdgcn_update_dpp(e, x, 0x130, 0xf, 0xf, false);                                   // wave_shl:1: lane i <- lane i+1, lane 63 keeps e
 }
 template <int N> __device__ __forceinline__ float shift_below_h(float x, float hv) { return __int_as_float(dpp_shift_below<N>(__float_as_int(x), __float_as_int(hv))); }
@@ -558,14 +561,16 @@ __device__ __forceinline__ f2v div2_ieee(f2v a, f2v b)
     return q;
 }
 
-template <int FD>
+template <int FD, bool TWO_OP>
 __device__ __forceinline__ void collide2_packed(const f2v (&fin)[9], const FastDiv &fdv, f2v (&fo)[9], f2v &rho, f2v &ux, f2v &uy)
 {
     f2v r, u, v;
     {   // moments (d2q9.hpp, html:335-338) with the two divisions packed
-        f2v rs = {0.0f, 0.0f};
+        // (0.0 + fin[0] of the reference's sum is fin[0] itself unless fin[0] = -0, and a density sum that starts at -0 instead of +0 ends on the same
+        //  value unless all nine populations are -0 — a state whose clamped density, 0.5, and NaN velocity are the same either way: the addition is dropped)
+        f2v rs = fin[0];
 #pragma unroll
-        for (int k = 0; k < 9; k++) rs += fin[k];
+        for (int k = 1; k < 9; k++) rs += fin[k];
         r = rs;
         u = div2_ieee(fin[1] + fin[5] + fin[8] - fin[3] - fin[6] - fin[7], rs);
         v = div2_ieee(fin[2] + fin[5] + fin[6] - fin[4] - fin[7] - fin[8], rs);
@@ -600,7 +605,7 @@ __device__ __forceinline__ void collide2_packed(const f2v (&fin)[9], const FastD
     f2v eq[9];
     feq_all<f2v>(r, u, v, eq);
     if (FD != 0 && fast) {
-        const f2v rt = {fdv.rtau, fdv.rtau}, ta = {fdv.tau, fdv.tau};
+        const f2v rt = {fdv.rtau, fdv.rtau}, ta = {fdv.tau, fdv.tau}, rl = {fdv.rlo, fdv.rlo};
         // three directions abreast: a packed fp32 instruction whose result the very next instruction needs costs a wait state (s_nop) —
         // written chain by chain the nine relaxations were a fifth of the loop's issue slots in nops
 #pragma unroll
@@ -608,12 +613,19 @@ __device__ __forceinline__ void collide2_packed(const f2v (&fin)[9], const FastD
             f2v x[3], q0[3], e[3], t[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) x[j] = fin[g + j] - eq[g + j];
+            if constexpr (TWO_OP) {      // div_by_tau_fast<true>: p = x rlo, q = fma(x, r, p)
 #pragma unroll
-            for (int j = 0; j < 3; j++) q0[j] = x[j] * rt;
+                for (int j = 0; j < 3; j++) q0[j] = x[j] * rl;
 #pragma unroll
-            for (int j = 0; j < 3; j++) e[j] = __builtin_elementwise_fma(-q0[j], ta, x[j]);
+                for (int j = 0; j < 3; j++) t[j] = __builtin_elementwise_fma(x[j], rt, q0[j]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 3; j++) t[j] = __builtin_elementwise_fma(e[j], rt, q0[j]);
+                for (int j = 0; j < 3; j++) q0[j] = x[j] * rt;
+#pragma unroll
+                for (int j = 0; j < 3; j++) e[j] = __builtin_elementwise_fma(-q0[j], ta, x[j]);
+#pragma unroll
+                for (int j = 0; j < 3; j++) t[j] = __builtin_elementwise_fma(e[j], rt, q0[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 3; j++) fo[g + j] = fin[g + j] - t[j];
         }
@@ -635,6 +647,7 @@ __device__ __forceinline__ void march_collide_sites(const MV<T, S> (&fin)[9], co
                                                     MV<T, S> &uy4)
 {
     constexpr int FDV = FD & 3;          // how to divide by tau (d2q9.hpp)
+    constexpr bool TWO = (FD & MARCH_FD_TWOOP) != 0;
     if constexpr (sizeof(T) == 4 && (FD & MARCH_FD_CONTRACTED) != 0) {
 #pragma unroll
         for (int v = 0; v < S; v++) {
@@ -650,7 +663,7 @@ __device__ __forceinline__ void march_collide_sites(const MV<T, S> (&fin)[9], co
         f2v a[9], f[9], r, u, w;
 #pragma unroll
         for (int k = 0; k < 9; k++) a[k] = f2v{fin[k].v[0], fin[k].v[1]};
-        collide2_packed<FDV>(a, fdv, f, r, u, w);
+        collide2_packed<FDV, TWO>(a, fdv, f, r, u, w);
 #pragma unroll
         for (int k = 0; k < 9; k++) { o[k].v[0] = f[k][0]; o[k].v[1] = f[k][1]; }
         rho4.v[0] = r[0]; rho4.v[1] = r[1]; ux4.v[0] = u[0]; ux4.v[1] = u[1]; uy4.v[0] = w[0]; uy4.v[1] = w[1];
@@ -672,7 +685,7 @@ __device__ __forceinline__ void march_collide_sites(const MV<T, S> (&fin)[9], co
             float a[9], f[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
-            if (FDV != 0 && fast) collide_tail<true>(a, fdv, r[v], u[v], w[v], s2[v], f);
+            if (FDV != 0 && fast) collide_tail<true, TWO>(a, fdv, r[v], u[v], w[v], s2[v], f);
             else collide_tail<false>(a, fdv, r[v], u[v], w[v], s2[v], f);
 #pragma unroll
             for (int k = 0; k < 9; k++) o[k].v[v] = f[k];
@@ -684,7 +697,7 @@ __device__ __forceinline__ void march_collide_sites(const MV<T, S> (&fin)[9], co
             T a[9], f[9], r, u, w;
 #pragma unroll
             for (int k = 0; k < 9; k++) a[k] = fin[k].v[v];
-            collide<T>(a, tau, f, r, u, w);
+            collide_t<T, FD>(a, fdv, tau, f, r, u, w);
 #pragma unroll
             for (int k = 0; k < 9; k++) o[k].v[v] = f[k];
             rho4.v[v] = r; ux4.v[v] = u; uy4.v[v] = w;

@@ -4,7 +4,7 @@
 // texture/FBO ping-pong -> two SoA lattices in HBM; simStep -> step kernels on a HIP stream;
 // readMacro/updateFieldsFromMacro/computeForces/renderField -> on-demand kernels.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include "rccl_bind.hpp"      // <rccl/rccl.h> for the types; the entry points are bound at run time to the one RCCL of the process
 
 #include <cmath>
 #include <cstdarg>
@@ -30,7 +30,9 @@
 using namespace wt;
 
 // Environment knobs.  Five are part of the interface (include/windtunnel.h: WT_FUSE2, WT_FUSE_CHUNK, WT_FAST_DIV, WT_CHAIN, WT_TUNE): they preset a
-// handle's options at wt_create and, like every option that decides the pass schedule, enter the cross-rank fingerprint (schedule_fingerprint).
+// handle's options at wt_create.  The four that decide the pass schedule (fuse_steps, fuse_chunk, fast_div, chain) enter the cross-rank fingerprint
+// through their options (schedule_fingerprint lists exactly what is compared); WT_TUNE / "tune" does NOT and must not — the measured cut is a rank's
+// own affair (its trial passes exchange nothing) — and neither do "trim_ghosts", "fast_div_two_op" and "exchange_timing" (ADVICE r4).
 // The others belong to the experiments under tools/ and exist only in a library built with -DWT_EXPERIMENT_KNOBS (`make lib EXPERIMENT=1`): a
 // production library cannot be steered into a plan its neighbours do not share by a stray environment variable.
 static inline const char *exp_env(const char *name)
@@ -146,8 +148,11 @@ struct wt_handle {
     // fast division by tau (d2q9.hpp): proved per tau on the device before it is used
     unsigned int *d_nbad = nullptr;
     float fd_tau = 0.0f;
-    bool fd_checked = false, fd_ok = false;
+    bool fd_checked = false, fd_ok = false;       // the three-operation division by tau is proved for fd_tau (d2q9.hpp)
+    bool fd2_ok = false;                          // ... and so is the two-operation one (the four-step fp32 kernel's; rank-local: same bits either way)
     bool fast_div = true;                // option "fast_div"
+    double selftest_tau = 0.58;          // option "selftest_tau": the tau the read-only options "selftest_fastdiv32_*" / "selftest_fastdiv64" check
+    bool two_op = true;                  // option "fast_div_two_op": the four-step fp32 kernel divides by tau in two operations where proved (d2q9.hpp)
     bool fast_math = false;              // option "fast_math": contracted collision in the marching kernels (opt-in; tolerance, not bit-equality)
     bool chain = true;                   // option "chain": plain-fluid workgroups share their units' edge columns (step_chain.hpp)
     int n_chain_units = 0;
@@ -173,6 +178,7 @@ struct wt_handle {
     double4 *cv_layer = nullptr;
     float *cv_text = nullptr;
     bool cv_text_set = false;
+    bool cv_layer_live = false;          // strokes have been drawn on the particle layer since it was last cleared (a canvas of ANOTHER scale would wipe them)
     uchar4 *cv_out = nullptr;
     double *cv_small = nullptr;          // polygon (up to CV_MAX_POLY points) + bar rows
     double *cv_seg = nullptr;
@@ -435,10 +441,25 @@ extern "C" int wt_get_info(const wt_handle *h, wt_info *info)
 }
 
 extern "C" const char *wt_last_error(void) { return g_err; }
-extern "C" const char *wt_version(void) { return "libwindtunnel 0.1 (gfx950, D2Q9 pull, column-major SoA)"; }
+// "libwindtunnel 0.2 (...); RCCL <version> at <path> (<how it was bound>)" — or "RCCL: not bound yet" before the first wt_comm_* call of the process
+extern "C" const char *wt_version(void)
+{
+    static thread_local std::string v;
+    v = "libwindtunnel 0.2 (gfx950, D2Q9 pull, column-major SoA); " + rccl_describe(false);
+    return v.c_str();
+}
+// every wt_comm_* entry point: bind RCCL (once per process) or say why not
+static int rccl_require()
+{
+    const RcclApi &a = rccl_api();
+    if (!a.bound) return fail(WT_ERR_RCCL, "%s", a.error.c_str());
+    return WT_OK;
+}
 
 // A chain unit that gave up waiting for its partner's hand-over (step_chain.hpp: the poll is bounded) has raised the host-mapped word: the
-// state it produced is not to be trusted.  Looked at wherever the host has just synchronised with the device.
+// state it produced is not to be trusted.  Looked at wherever the host has just synchronised with the device AND returns data: wt_sync, every
+// read-back (populations, macro planes, fields, colours, the canvas), the reductions (ranges, forces, clamp events), the tracers and the timed
+// stepping calls; wt_init_equilibrium and wt_write_f — which replace the state — clear it.
 static int check_stuck(wt_handle *h)
 {
     if (h->stuck_host && *h->stuck_host != 0)
@@ -607,7 +628,7 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
         HIP_TRY(hipMemsetAsync(h->bcode, 0, cbytes, h->s_compute));
         h->device_bytes += (long long)cbytes;
     }
-    if (!h->d_nbad) HIP_TRY(hipMalloc((void **)&h->d_nbad, sizeof(unsigned int)));
+    if (!h->d_nbad) HIP_TRY(hipMalloc((void **)&h->d_nbad, 2 * sizeof(unsigned int)));
     h->n_win = nwin;
     h->march_s = sites;
     h->march_depth = depth;
@@ -848,6 +869,15 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->fast_div = value != 0.0;
         return WT_OK;
     }
+    if (strcmp(name, "selftest_tau") == 0) {
+        if (!(value > 0.0) || !std::isfinite(value)) return fail(WT_ERR_ARG, "selftest_tau must be positive and finite");
+        h->selftest_tau = value;
+        return WT_OK;
+    }
+    if (strcmp(name, "fast_div_two_op") == 0) {       // rank-local (the same bits either way): not part of the cross-rank fingerprint
+        h->two_op = value != 0.0;
+        return WT_OK;
+    }
     if (strcmp(name, "chain") == 0) {
         h->chain = value != 0.0;
         return rebuild_fuse_plan(h);
@@ -918,7 +948,37 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
                  : strcmp(name, "interior_ms") == 0 ? h->xt_interior_ms : h->xt_exposed_ms;
         return WT_OK;
     }
-    if (strcmp(name, "fast_div_active") == 0) { *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "fast_div_active") == 0) {
+        // fp32: the proof accepted the tau of the last stepping call; fp64: the four-operation sequence is on (a theorem for every tau, d2q9.hpp)
+        if (h->dtype != WT_F32) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
+        *value = (h->fd_checked && h->fd_ok && h->fast_div) ? 1.0 : 0.0;
+        return WT_OK;
+    }
+    if (strcmp(name, "fast_div_two_op") == 0) { *value = h->two_op ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "canvas_scale") == 0) { *value = h->cv_scale; return WT_OK; }                    // 0: no canvas allocated yet
+    if (strcmp(name, "canvas_text_set") == 0) { *value = h->cv_text_set ? 1.0 : 0.0; return WT_OK; }  // the label map of the present canvas has been uploaded
+    if (strcmp(name, "canvas_layer_live") == 0) { *value = h->cv_layer_live ? 1.0 : 0.0; return WT_OK; }
+    if (strncmp(name, "selftest_fastdiv", 16) == 0) {
+        // mismatches of the fast divisions by "selftest_tau" against the IEEE quotient, counted on the device (tests/test_gpu_fastdiv.py):
+        //   selftest_fastdiv32_3 / _2: the three- / two-operation binary32 forms over all 2^23 significands and both signs (the library's own proof);
+        //   selftest_fastdiv64: the four-operation binary64 form on 2^28 pseudo-random and boundary-hugging numerators
+        wt_handle *hm = const_cast<wt_handle *>(h);
+        const FastDiv fdv = make_fastdiv(strcmp(name, "selftest_fastdiv64") == 0 ? h->selftest_tau : (double)(float)h->selftest_tau);
+        if (hipSetDevice(h->device) != hipSuccess) return fail(WT_ERR_HIP, "hipSetDevice");
+        if (!hm->d_nbad && hipMalloc((void **)&hm->d_nbad, 2 * sizeof(unsigned int)) != hipSuccess) return fail(WT_ERR_HIP, "selftest: hipMalloc");
+        if (hipMemsetAsync(hm->d_nbad, 0, 2 * sizeof(unsigned int), h->s_compute) != hipSuccess) return fail(WT_ERR_HIP, "selftest: memset");
+        const bool f64 = strcmp(name, "selftest_fastdiv64") == 0;
+        if (f64) hipLaunchKernelGGL(k_check_fastdiv64, dim3(1024), dim3(256), 0, h->s_compute, fdv, 0x5eedULL, 1024, hm->d_nbad);
+        else if (strcmp(name, "selftest_fastdiv32_3") == 0 || strcmp(name, "selftest_fastdiv32_2") == 0)
+            hipLaunchKernelGGL(k_verify_fastdiv, dim3(1024), dim3(256), 0, h->s_compute, fdv, hm->d_nbad);
+        else return fail(WT_ERR_ARG, "unknown option '%s'", name);
+        unsigned int nbad[2] = {1, 1};
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(nbad, hm->d_nbad, sizeof(nbad), hipMemcpyDeviceToHost, h->s_compute) != hipSuccess ||
+            hipStreamSynchronize(h->s_compute) != hipSuccess) return fail(WT_ERR_HIP, "selftest: launch");
+        *value = (double)nbad[(!f64 && name[strlen(name) - 1] == '2') ? 1 : 0];
+        return WT_OK;
+    }
+    if (strcmp(name, "fast_div_two_op_active") == 0) { *value = (h->dtype == WT_F32 && h->fd_checked && h->fd_ok && h->fd2_ok && h->fast_div && h->two_op) ? 1.0 : 0.0; return WT_OK; }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
 
@@ -1207,26 +1267,38 @@ static int step_once(wt_handle *h, double tau, double u0, bool emit)
     return step_compute(h, tau, u0, emit, refresh);
 }
 
-// Is the three-operation division by tau exact for this tau?  Exhaustive check over all 2^23 significands on the
-// device (d2q9.hpp), once per tau; the answer selects the kernel instantiation.
-static int fastdiv_for(wt_handle *h, float tau, bool *use)
+// Are the three- and the two-operation division by tau exact for this tau?  Exhaustive check over all 2^23 significands on the
+// device (d2q9.hpp), once per tau; the answers select the kernel instantiation (`use`: the three-operation form, which every rank
+// agrees on — agree_fastdiv —; `use2`: the two-operation form of the four-step fp32 kernel, a rank's own affair: the same bits).
+static int fastdiv_for(wt_handle *h, float tau, bool *use, bool *use2 = nullptr)
 {
     *use = false;
+    if (use2) *use2 = false;
     if (!h->fast_div) return WT_OK;
     if (!h->fd_checked || h->fd_tau != tau) {
-        const float rtau = 1.0f / tau;
-        HIP_TRY(hipMemsetAsync(h->d_nbad, 0, sizeof(unsigned int), h->s_compute));
-        hipLaunchKernelGGL(k_verify_fastdiv, dim3(1024), dim3(256), 0, h->s_compute, tau, rtau, h->d_nbad);
+        const FastDiv fdv = make_fastdiv((double)tau);
+        HIP_TRY(hipMemsetAsync(h->d_nbad, 0, 2 * sizeof(unsigned int), h->s_compute));
+        hipLaunchKernelGGL(k_verify_fastdiv, dim3(1024), dim3(256), 0, h->s_compute, fdv, h->d_nbad);
         HIP_TRY(hipGetLastError());
-        unsigned int nbad = 1;
-        HIP_TRY(hipMemcpyAsync(&nbad, h->d_nbad, sizeof(nbad), hipMemcpyDeviceToHost, h->s_compute));
+        unsigned int nbad[2] = {1, 1};
+        HIP_TRY(hipMemcpyAsync(nbad, h->d_nbad, sizeof(nbad), hipMemcpyDeviceToHost, h->s_compute));
         HIP_TRY(hipStreamSynchronize(h->s_compute));
+        const bool range_ok = std::isfinite(fdv.rtau) && tau >= 0x1p-20f && tau <= 0x1p20f;
         h->fd_tau = tau;
-        h->fd_ok = (nbad == 0) && std::isfinite(rtau) && tau >= 0x1p-20f && tau <= 0x1p20f;
+        h->fd_ok = (nbad[0] == 0) && range_ok;
+        h->fd2_ok = h->fd_ok && (nbad[1] == 0);
         h->fd_checked = true;
     }
     *use = h->fd_ok;
+    if (use2) *use2 = h->fd_ok && h->fd2_ok && h->two_op;
     return WT_OK;
+}
+static inline FastDiv fastdiv_params(const wt_handle *h, double tau)
+{
+    FastDiv f = make_fastdiv(tau);
+    // fp64: the four-operation sequence is a theorem for every tau (d2q9.hpp); kept away from tau so close to the range limits that 1/tau is not normal
+    f.on64 = (h->fast_div && std::isfinite(f.rhi64) && tau >= 0x1p-20 && tau <= 0x1p20) ? 1 : 0;
+    return f;
 }
 
 template <typename T, int S, bool EMIT, int FD>
@@ -1250,7 +1322,7 @@ static int step_pair_fused_t(wt_handle *h, double tau, double u0, bool emit)
     p.g = g;
     p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(T));
     p.nwin_total = h->n_win;
-    p.fdv.tau = (float)tau; p.fdv.rtau = 1.0f / (float)tau;
+    p.fdv = fastdiv_params(h, tau);
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)((h->steps_done >> 1) & 1);
@@ -1348,7 +1420,7 @@ static int trim_plan_for(wt_handle *h, int v_after, const MarchUnit **units, int
 // Three steps in one pass (step_march3.hpp), or two on the same tables (depth = 2: what a step count leaves over).
 // A = f[cur] (time t), B = f[1-cur] (receives time t + depth).
 template <typename T, int S, int FD>
-static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, int depth)
+static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, int depth, bool two_op = false)
 {
     const Geom &g = h->g;
     MarchParams<T> p;
@@ -1361,7 +1433,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.g = g;
     p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(T));
     p.nwin_total = h->n_win;
-    p.fdv.tau = (float)tau; p.fdv.rtau = 1.0f / (float)tau;
+    p.fdv = fastdiv_params(h, tau);
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)(h->passes & 1);
@@ -1400,6 +1472,14 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
         if (depth == 4) {
             // (fp32 with the IEEE division by tau: not built — 40-80 bytes of scratch per lane; set_tau_cap keeps such a call at three steps per pass)
             if constexpr (sizeof(T) == 4 && FD == 0) return fail(WT_ERR_STATE, "internal: four-step pass with the IEEE division");
+            else if constexpr (sizeof(T) == 4 && FD == 1) {
+                // the division by tau in two operations where the device has proved it for this tau (fastdiv_for), in three otherwise
+                if (two_op) {
+                    if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD | MARCH_FD_TWOOP>), grid, dim3(256), 0, st, p);
+                    else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD | MARCH_FD_TWOOP>), grid, dim3(256), 0, st, p);
+                } else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
+            }
             else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
         } else if (depth == 3) {
@@ -1448,11 +1528,11 @@ static inline int fuse_stride(const wt_handle *h, int left)
 static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
 {
     if (h->march_depth >= 3) {
-        if (h->dtype != WT_F32) return step_triple_fused_t<double, 1, 0>(h, tau, u0, emit, k);
+        if (h->dtype != WT_F32) return step_triple_fused_t<double, 1, 1>(h, tau, u0, emit, k);      // (FD 1: the guarded four-operation division, switched by fdv.on64)
         if (h->fast_math) return step_triple_fused_t<float, 2, MARCH_FD_CONTRACTED>(h, tau, u0, emit, k);
-        bool fd = false;
-        WT_TRY(fastdiv_for(h, (float)tau, &fd));
-        return fd ? step_triple_fused_t<float, 2, 1>(h, tau, u0, emit, k) : step_triple_fused_t<float, 2, 0>(h, tau, u0, emit, k);
+        bool fd = false, fd2 = false;
+        WT_TRY(fastdiv_for(h, (float)tau, &fd, &fd2));
+        return fd ? step_triple_fused_t<float, 2, 1>(h, tau, u0, emit, k, fd2) : step_triple_fused_t<float, 2, 0>(h, tau, u0, emit, k);
     }
     return step_pair_fused(h, tau, u0, emit);
 }
@@ -1647,10 +1727,11 @@ static int agree_mismatch(const wt_handle *h, const SchedField &f, long long lo,
 // together (nobody is left waiting in an exchange).  COLLECTIVE: made inside wt_comm_init_rank and at the first stepping call after a schedule
 // input changed — wt_set_option / wt_set_mask / wt_init_equilibrium / wt_write_f on a slab handle are collective in that sense (every rank
 // makes the same call), as they always had to be.
+// `agree_dirty` is cleared only once the comparison has SUCCEEDED: after a refusal, or a HIP / RCCL error inside the check, the next stepping call
+// checks again and is refused again (cleared up front, a refused handle could be stepped unchecked — over RCCL, the hang this exists for).
 static int agree_rccl(wt_handle *h, const char *when)
 {
-    h->agree_dirty = false;
-    if (!h->agree_check || h->transport != TR_RCCL) return WT_OK;
+    if (!h->agree_check || h->transport != TR_RCCL) { h->agree_dirty = false; return WT_OK; }
     SchedField f[SCHED_FIELDS_MAX];
     const int n = schedule_fingerprint(h, f);
     long long host[2 * SCHED_FIELDS_MAX];
@@ -1663,16 +1744,19 @@ static int agree_rccl(wt_handle *h, const char *when)
     h->agree_checks += 1;
     for (int i = 0; i < n; i++)
         if (host[i] != -host[n + i]) return agree_mismatch(h, f[i], -host[n + i], host[i], when);
+    h->agree_dirty = false;
     return WT_OK;
 }
 
-// TR_LOCAL: the same table compared on the host over the handles of the group.
+// TR_LOCAL: the same table compared on the host over the handles of the group.  (The flags stay set on a refusal: the next call checks again.)
 static int agree_local(wt_handle **hs, int n_h, const char *when)
 {
     bool due = false, on = true;
     for (int r = 0; r < n_h; r++) { due = due || hs[r]->agree_dirty; on = on && hs[r]->agree_check; }
-    for (int r = 0; r < n_h; r++) hs[r]->agree_dirty = false;
-    if (!due || !on || n_h < 2) return WT_OK;
+    if (!due || !on || n_h < 2) {
+        for (int r = 0; r < n_h; r++) hs[r]->agree_dirty = false;
+        return WT_OK;
+    }
     SchedField f0[SCHED_FIELDS_MAX], fr[SCHED_FIELDS_MAX];
     const int n = schedule_fingerprint(hs[0], f0);
     for (int r = 1; r < n_h; r++) {
@@ -1680,7 +1764,7 @@ static int agree_local(wt_handle **hs, int n_h, const char *when)
         for (int i = 0; i < n; i++)
             if (fr[i].v != f0[i].v) return agree_mismatch(hs[r], fr[i], std::min(fr[i].v, f0[i].v), std::max(fr[i].v, f0[i].v), when);
     }
-    for (int r = 0; r < n_h; r++) hs[r]->agree_checks += 1;
+    for (int r = 0; r < n_h; r++) { hs[r]->agree_checks += 1; hs[r]->agree_dirty = false; }
     return WT_OK;
 }
 
@@ -1794,7 +1878,7 @@ extern "C" int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, fl
     HIP_TRY(hipEventRecord(h->ev_b, h->s_compute));
     HIP_TRY(hipEventSynchronize(h->ev_b));
     HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev_a, h->ev_b));
-    return WT_OK;
+    return check_stuck(h);                              // (the host has just synchronised with the device: look at the word the bounded poll raises)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1803,6 +1887,7 @@ extern "C" int wt_step_timed(wt_handle *h, int nsteps, double tau, double u0, fl
 extern "C" int wt_comm_unique_id(void *id_out)
 {
     if (!id_out) return fail(WT_ERR_ARG, "id_out is null");
+    WT_TRY(rccl_require());
     static_assert(sizeof(ncclUniqueId) <= WT_COMM_ID_BYTES, "ncclUniqueId larger than WT_COMM_ID_BYTES");
     ncclUniqueId id;
     NCCL_TRY(ncclGetUniqueId(&id));
@@ -1817,15 +1902,30 @@ extern "C" int wt_comm_init_rank(wt_handle *h, const void *id_in)
     if (!id_in) return fail(WT_ERR_ARG, "id is null");
     if (h->nranks < 2) return fail(WT_ERR_STATE, "not a slab handle");
     if (h->transport != TR_NONE) return fail(WT_ERR_STATE, "handle already has a transport");
+    WT_TRY(rccl_require());
     HIP_TRY(hipSetDevice(h->device));
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof(id));
     NCCL_TRY(ncclCommInitRank(&h->comm, h->nranks, id, h->rank));
     h->transport = TR_RCCL;
-    NCCL_TRY(ncclCommCount(h->comm, &h->comm_ranks));
-    if (h->comm_ranks != h->nranks) return fail(WT_ERR_RCCL, "the communicator holds %d ranks, the tunnel has %d slabs", h->comm_ranks, h->nranks);
+    int rc = WT_OK;
+    {
+        const ncclResult_t r = ncclCommCount(h->comm, &h->comm_ranks);
+        if (r != ncclSuccess) rc = fail(WT_ERR_RCCL, "ncclCommCount failed: %s", ncclGetErrorString(r));
+        else if (h->comm_ranks != h->nranks) rc = fail(WT_ERR_RCCL, "the communicator holds %d ranks, the tunnel has %d slabs", h->comm_ranks, h->nranks);
+    }
     // every rank proves, before the first exchange, that it will take the schedule its neighbours take
-    return agree_rccl(h, "wt_comm_init_rank");
+    if (rc == WT_OK) rc = agree_rccl(h, "wt_comm_init_rank");
+    if (rc != WT_OK) {
+        // a refused handle must not stay steppable: the communicator is torn down and the handle is back to "no transport" — every rank
+        // reaches this branch together (the agreement table is the same on all of them), so nobody is left inside a collective
+        (void)ncclCommDestroy(h->comm);
+        h->comm = nullptr;
+        h->transport = TR_NONE;
+        h->comm_ranks = 0;
+        h->agree_dirty = true;
+    }
+    return rc;
 }
 
 // RCCL plumbing check on ONE GPU: a one-rank communicator, then the same grouped
@@ -1834,6 +1934,7 @@ extern "C" int wt_comm_init_rank(wt_handle *h, const void *id_in)
 extern "C" int wt_comm_selftest(int device, int ny)
 {
     if (ny < 1 || ny > (1 << 20)) return fail(WT_ERR_ARG, "ny out of range");
+    WT_TRY(rccl_require());
     HIP_TRY(hipSetDevice(device));
     ncclUniqueId id;
     NCCL_TRY(ncclGetUniqueId(&id));
@@ -2028,6 +2129,7 @@ extern "C" int wt_step_group_timed(wt_handle **hs, int n, int nsteps, double tau
         HIP_TRY(hipEventSynchronize(hs[r]->ev_b));
         HIP_TRY(hipEventElapsedTime(&elapsed_ms[r], hs[r]->ev_a, hs[r]->ev_b));
     }
+    for (int r = 0; r < n; r++) WT_TRY(check_stuck(hs[r]));
     return WT_OK;
 }
 
@@ -2095,6 +2197,7 @@ extern "C" int wt_write_f(wt_handle *h, const void *f_in)
         h->cur = 0;
     }
     WT_TRY(h->dtype == WT_F32 ? write_f_impl<float>(h, f_in) : write_f_impl<double>(h, f_in));
+    if (h->stuck_host) { HIP_TRY(hipStreamSynchronize(h->s_compute)); *h->stuck_host = 0; }       // the state is replaced, as by wt_init_equilibrium
     h->inited = true;
     h->seams_valid = false;
     h->macro_stale = true;   // the macro planes still hold the previous state's (rho,ux,uy)
@@ -2158,7 +2261,7 @@ extern "C" int wt_reduce_ranges(wt_handle *h, double u0, double *max_s, double *
         if (hp[b].cp_max > cmax) cmax = hp[b].cp_max;
     }
     *max_s = mx; *cp_min = cmin; *cp_max = cmax;
-    return WT_OK;
+    return check_stuck(h);
 }
 
 extern "C" int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, int64_t *rev)
@@ -2186,7 +2289,7 @@ extern "C" int wt_forces(wt_handle *h, double *fx, double *fy, int64_t *surf, in
     long long ns = 0, nr = 0;
     for (int b = 0; b < nb; b++) { sx += hp[b].fx; sy += hp[b].fy; ns += hp[b].surf; nr += hp[b].rev; }
     *fx = sx; *fy = sy; *surf = ns; *rev = nr;
-    return WT_OK;
+    return check_stuck(h);
 }
 
 extern "C" int wt_clamp_events(wt_handle *h, int64_t *rho_events, int64_t *u_events)
@@ -2211,7 +2314,7 @@ extern "C" int wt_clamp_events(wt_handle *h, int64_t *rho_events, int64_t *u_eve
     long long nr = 0, nu = 0;
     for (int b = 0; b < nb; b++) { nr += hp[b].rho_events; nu += hp[b].u_events; }
     *rho_events = nr; *u_events = nu;
-    return WT_OK;
+    return check_stuck(h);
 }
 
 // Vorticity (html:411-417) needs uy of the columns left and right of the slab: fetch the
@@ -2271,7 +2374,7 @@ static int field_impl(wt_handle *h, int mode, double u0, double max_s, double cp
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    return WT_OK;
+    return check_stuck(h);
 }
 
 extern "C" int wt_field(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
@@ -2302,7 +2405,7 @@ static int render_impl(wt_handle *h, int mode, double u0, double max_s, double c
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->stage, bytes, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    return WT_OK;
+    return check_stuck(h);
 }
 
 extern "C" int wt_render_rgba(wt_handle *h, int mode, double u0, double max_s, double cp_min, double cp_max,
@@ -2355,7 +2458,7 @@ extern "C" int wt_advect_tracers(wt_handle *h, int n, const double *x, const dou
     HIP_TRY(hipMemcpyAsync(speed, os, nd, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipMemcpyAsync(ok, dok, (size_t)n, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    return WT_OK;
+    return check_stuck(h);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2369,6 +2472,11 @@ static int canvas_ensure(wt_handle *h, int scale)
     if (scale < 1 || scale > CV_MAX_SCALE) return fail(WT_ERR_ARG, "canvas scale must be 1 .. %d", CV_MAX_SCALE);
     if (h->nranks > 1) return fail(WT_ERR_STATE, "the canvas needs the whole lattice on one handle");
     if (h->cv_scale == scale) return WT_OK;
+    // a handle holds ONE canvas at one scale; re-allocating it at another scale frees the particle layer and the text map.  With strokes on the
+    // layer that would silently wipe a caller's trails: refused until the layer has been cleared (fade = 2) at its own scale.
+    if (h->cv_scale != 0 && h->cv_layer_live)
+        return fail(WT_ERR_STATE, "this handle's canvas lives at scale %d with tracer strokes on its particle layer; a canvas at scale %d would wipe them: "
+                                  "clear the layer first (wt_canvas_stroke(h, %d, 2, 0, NULL)) or compose at scale %d", h->cv_scale, scale, h->cv_scale, h->cv_scale);
     const CanvasDims d = canvas_dims(scale);
     const size_t npx = (size_t)d.w * d.h;
     if (h->cv_layer) { HIP_TRY(hipFree(h->cv_layer)); h->cv_layer = nullptr; }
@@ -2382,6 +2490,7 @@ static int canvas_ensure(wt_handle *h, int scale)
     HIP_TRY(hipMemsetAsync(h->cv_layer, 0, npx * sizeof(double4), h->s_compute));
     HIP_TRY(hipMemsetAsync(h->cv_text, 0, npx * sizeof(float), h->s_compute));
     h->cv_text_set = false;
+    h->cv_layer_live = false;
     h->cv_scale = scale;
     return WT_OK;
 }
@@ -2406,6 +2515,8 @@ extern "C" int wt_canvas_stroke(wt_handle *h, int scale, int fade, int n, const 
         HIP_TRY(hipMemcpyAsync(h->cv_seg, seg, bytes, hipMemcpyHostToDevice, h->s_compute));
     }
     if (fade == 0 && n == 0) return WT_OK;
+    if (fade == 2) h->cv_layer_live = false;                      // cleared ...
+    if (n > 0) h->cv_layer_live = true;                           // ... and drawn on
     hipLaunchKernelGGL(k_canvas_stroke, dim3((unsigned)((d.w + 7) / 8), (unsigned)((d.h + 7) / 8)), dim3(64), 0, h->s_compute, h->cv_layer, d, fade, n,
                        (const double *)h->cv_seg);
     HIP_TRY(hipGetLastError());
@@ -2460,5 +2571,5 @@ extern "C" int wt_canvas_compose(wt_handle *h, int scale, int mode, double u0, d
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rgba_out, h->cv_out, npx * 4, hipMemcpyDeviceToHost, h->s_compute));
     HIP_TRY(hipStreamSynchronize(h->s_compute));
-    return WT_OK;
+    return check_stuck(h);
 }

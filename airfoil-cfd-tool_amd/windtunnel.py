@@ -245,7 +245,10 @@ class WindTunnel:
         fx, fy = cv.w2c(self.geometry.xp, self.geometry.yp, self.y_half_world())
         key = (int(scale), mode, float(self.aoa_deg), float(self.y_half_world()))
         text = None
-        if key != getattr(self, "_canvas_text_key", None):             # the labels change with the angle, the field and the scale only
+        # the labels change with the angle, the field and the scale only — and must be sent again whenever the library's canvas holds no label map:
+        # a canvas (re-)allocated at this scale starts without one, whatever this object remembers
+        if (key != getattr(self, "_canvas_text_key", None) or int(self.engine.get_option("canvas_scale")) != int(scale)
+                or not self.engine.get_option("canvas_text_set")):
             text = compose.text_alpha_map(scale, self.aoa_deg, mode, self.y_half_world())
         img = self.engine.canvas_compose(scale, mode, self.u0, self.max_s, self.cp_min, self.cp_max, VORT_SCALE, np.column_stack([fx, fy]),
                                          compose.bar_rows(mode, scale), text, trails is not None)

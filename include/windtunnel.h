@@ -121,9 +121,19 @@ WT_API const char *wt_version(void);
  *       handle that stands in for one slab of a split plans like that split's narrowest slab (distributed.measure_slab_cost).
  *   "fuse_chunk": cost limit of one marching unit in columns (0 = the default: units cut by TIME into one resident round).
  *   "fuse_sites": kept for callers of round 2; the sites per lane are fixed by the element type (fp32 2, fp64 1).
- *   "fast_div" (default 1): divide by tau through a reciprocal and two fused multiply-adds where an exhaustive on-device check over
- *       all 2^23 significands has PROVED the sequence equal to the IEEE quotient for this tau (csrc/d2q9.hpp); 0 keeps the IEEE
- *       division everywhere.  fp32 only (fp64 always divides in IEEE arithmetic).
+ *   "fast_div" (default 1): divide by tau through a reciprocal and fused multiply-adds instead of the IEEE division (csrc/d2q9.hpp); 0 keeps the
+ *       IEEE division everywhere.  fp32: three operations (q0 = x r, e = fma(-q0, tau, x), q = fma(e, r, q0)) where an exhaustive on-device
+ *       check over all 2^23 significands has PROVED the sequence equal to the IEEE quotient for this tau.  fp64 (round 5): four operations
+ *       (p = x rlo, q1 = fma(x, rhi, p), e = fma(-q1, tau, x), q = fma(e, rhi, q1)) whose equality with the IEEE quotient is a theorem for
+ *       every tau (a faithful quotient corrected once with a correctly rounded reciprocal: Markstein), guarded like the fp32 one against
+ *       non-finite and huge populations (those waves divide in IEEE arithmetic).
+ *   "fast_div_two_op" (default 1, fp32, four steps per pass): where the same exhaustive check has ALSO proved the two-operation form
+ *       (p = x rlo, q = fma(x, r, p) with r + rlo = 1/tau to 2^-48) for this tau, the four-step kernel uses it; about 1 tau in 120 fails it
+ *       and keeps the three-operation form.  Rank-local (not part of the cross-rank check): the same bits either way.
+ *       "fast_div_two_op_active" reports the choice for the tau of the last stepping call.
+ *   "selftest_tau" + the read-only "selftest_fastdiv32_3" / "selftest_fastdiv32_2" / "selftest_fastdiv64": mismatches of the three fast
+ *       divisions against the IEEE quotient for that tau, counted on the device — the binary32 forms over all 2^23 significands and both
+ *       signs, the binary64 form on 2^28 pseudo-random and boundary-hugging numerators (tests/test_gpu_fastdiv.py).
  *   "fast_math" (default 0, fp32, OPT-IN, NOT bit-identical): the marching kernels collide with contracted arithmetic — fused
  *       multiply-adds, v_rcp / v_rsq for the divisions and the square root (csrc/d2q9.hpp collide_contracted).  Held to BASELINE.md's
  *       tolerance against the oracle (|d rho| <= 1e-5, |d u| <= 5e-6; tests/test_gpu_fast_math.py), +19 % on 4096^2, +36 % on a
@@ -144,6 +154,12 @@ WT_API const char *wt_version(void);
  *       wt_comm_init_rank and again at the first stepping call after wt_set_option / wt_set_mask / wt_init_equilibrium / wt_write_f (which
  *       are collective on slab handles: every rank makes the same call), by a host comparison in wt_step_group; a mismatch fails with
  *       WT_ERR_STATE naming the field and both values.  The fast-division verdict for a tau is agreed the same way (all-reduce(min)).
+ *       A refused check stays due: the next stepping call checks again (and is refused again until the ranks agree); a handle refused inside
+ *       wt_comm_init_rank has its communicator destroyed and is back to "no transport".
+ *       Fingerprinted: nx, ny, nranks, halo, dtype, the split, fuse_steps, fuse_depth, fuse_chunk, chain, fast_div, fast_math, plan_columns,
+ *       refresh, the device's resident wave slots, eligibility, mask set, the planner's outcome (plan ready, steps per pass, pass cap), steps
+ *       done, exact ghost columns.  Deliberately rank-local, i.e. NOT compared: "tune" / WT_TUNE and the cut it measures (its trial passes
+ *       exchange nothing), "trim_ghosts" (which ghost columns a rank bothers to march), "fast_div_two_op", "exchange_timing".
  *       0 is for tests that mix plans on purpose.  "agree_checks" counts the checks made.
  *   "exchange_timing" (default 0, slab handles): HIP events around every ghost exchange (comm stream) and around the interior kernel and the
  *       wait that follows it (compute stream); summed over the refresh steps since the option was set by "exchange_ms", "interior_ms",
@@ -155,7 +171,8 @@ WT_API const char *wt_version(void);
  * the handle's communicator), "wave_slots", "passes" and "single_steps" (fused passes / whole k_step steps since the last
  * wt_init_equilibrium or wt_write_f).
  *
- * Environment.  Five variables preset a handle's options at wt_create and are part of the interface (and of the cross-rank check above):
+ * Environment.  Five variables preset a handle's options at wt_create and are part of the interface; four of them enter the cross-rank check
+ * above through the option they set, WT_TUNE does not (the measured cut is a rank's own affair):
  *   WT_FUSE2=0|1|2 ("fuse_steps"), WT_FUSE_CHUNK=n ("fuse_chunk"), WT_FAST_DIV=0|1 ("fast_div"), WT_CHAIN=0|1 ("chain"), WT_TUNE=0|1 ("tune").
  * Nothing else in the environment reaches a production library.  The planner constants and launch orders the experiments under tools/ vary
  * (WT_PLAN_TIMED, WT_ALPHA, WT_ALPHA_SOLID, WT_BETA, WT_MAX_CHAIN, WT_MARCH_WAVES, WT_MARCH_ROUNDS, WT_MARCH_REV, WT_DEPTH3_MIN, WT_DEPTH4_MIN,
@@ -167,7 +184,12 @@ WT_API int wt_get_option(const wt_handle *h, const char *name, double *value);
 
 /* RCCL over xGMI, one process per GPU: rank 0 calls wt_comm_unique_id, the host
  * broadcasts the WT_COMM_ID_BYTES bytes (e.g. torch.distributed), then EVERY
- * rank calls wt_comm_init_rank (collective). */
+ * rank calls wt_comm_init_rank (collective).
+ * WHICH RCCL: the library has no link-time dependency on one.  The first wt_comm_* call of the process binds the ncclXxx entry points to the
+ * ONE RCCL the process holds — the symbols already in the global scope (an LD_PRELOADed stand-in), else the single librccl.so* in
+ * /proc/self/maps (PyTorch's copy once torch is imported), else dlopen("librccl.so.1") through the library's run path (/opt/rocm/lib) — and
+ * wt_version() then names its version and path.  Two different librccl.so* files mapped at that moment make every wt_comm_* call return
+ * WT_ERR_RCCL naming both (csrc/rccl_bind.hpp, tests/test_rccl_binding.py): a process must not talk to two RCCL instances by accident. */
 #define WT_COMM_ID_BYTES 128
 WT_API int wt_comm_unique_id(void *id_out);
 WT_API int wt_comm_init_rank(wt_handle *h, const void *id);

@@ -78,6 +78,14 @@ def main():
         eng.comm_init_rank(ids[0])
     except pkg.WTError as e:
         refused = e.code == -5 and "disagree" in str(e) and "fuse_depth" in str(e)
+    # ... and the refused handle is not left steppable: its communicator is gone, a stepping call says "no transport" instead of entering an exchange
+    if refused:
+        eng.set_mask(mask); eng.init_equilibrium(0.06)
+        try:
+            eng.step(2 * halo + 4, 0.58, 0.06)
+            refused = False
+        except pkg.WTError as e:
+            refused = e.code == -5 and "no transport" in str(e) and int(eng.get_option("comm_ranks")) == 0
     eng.close()
     got = [None] * world
     dist.all_gather_object(got, refused)

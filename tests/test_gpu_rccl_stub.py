@@ -58,6 +58,40 @@ def test_bench_two_ranks_end_to_end_over_the_stand_in_transport(stub):
     assert len({(x["fuse_depth"], x["pass_depth"]) for x in d["ranks"]}) == 1
 
 
+def test_bench_two_ranks_without_a_launcher_over_the_stand_in_transport(stub):
+    """`python bench.py --gpus 2` launched exactly like the N = 1 line (no torch.distributed.run in front, WORLD_SIZE unset): bench.py starts the
+    two ranks itself as a child job before it touches the GPU and the N = 2 line comes out, exchange-cost model included."""
+    env = {k: v for k, v in _env(stub, WT_BENCH_FORCE_DEVICE="0", WT_BENCH_TORCH_BACKEND="gloo").items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "WT_BENCH_SELF_LAUNCHED")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "2048", "--ny", "1024", "--steps", "58", "--warmup", "29", "--cpu-steps", "0",
+           "--balance", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "starting 2 ranks as a child job" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["comm_ranks_seen"] == [2] and [x["rank"] for x in d["ranks"]] == [0, 1]
+    for x in d["ranks"]:
+        # the exchange-cost model of the line (VERDICT r4 item 3): 9 populations x halo columns x pitch x element size per side and refresh
+        assert x["exchange_bytes_each"] == 9 * 29 * 1024 * 4 and x["exchange_model_us"] > 0 and x["exchange_sides"] == 1
+
+
+def test_bench_self_launch_on_one_gpu_fails_cleanly():
+    """The same launcher-less command WITHOUT the stand-in on this one-GPU box: rank 1 finds no second device -> its one-line diagnosis, a non-zero
+    status relayed by the parent, no bench line, nothing retried."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs: the command runs to the end")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "WT_BENCH_SELF_LAUNCHED", "LD_PRELOAD")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "1024", "--ny", "512", "--steps", "8", "--warmup", "4", "--cpu-steps", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+    assert "[bench.py] rank 1 (device 1) FAILED" in r.stderr and "the 2-rank job exited with status" in r.stderr
+    assert r.stderr.count("starting 2 ranks as a child job") == 1
+    assert [ln for ln in r.stdout.splitlines() if ln.startswith("{")] == []
+
+
 @pytest.mark.parametrize("world,dtype", [(3, "float32"), (2, "float64")])
 def test_slab_wind_tunnel_host_class_over_the_stand_in_transport(stub, world, dtype):
     """distributed.SlabWindTunnel on real slab engines: frame loop, AoA slider, combined reductions, gathered read-backs, and the vorticity field

@@ -284,6 +284,12 @@ def test_slabs_that_would_take_different_schedules_are_refused(pkg):
                 pkg.Engine.step_group(es, 20, 0.58, 0.06)
             assert ei.value.code == -5 and "disagree" in str(ei.value) and needle in str(ei.value), str(ei.value)
             assert all(e.info().steps_done == 0 for e in es)                      # refused before anything ran
+            # a retry WITHOUT touching any option is refused the same way (the check used to be marked done before its verdict,
+            # and the second call of a refused group ran unchecked)
+            with pytest.raises(pkg.WTError) as ei2:
+                pkg.Engine.step_group(es, 20, 0.58, 0.06)
+            assert ei2.value.code == -5 and "disagree" in str(ei2.value) and needle in str(ei2.value), str(ei2.value)
+            assert all(e.info().steps_done == 0 for e in es)
             es[1].set_option(knob, v0)                                            # put right: the next call checks again and runs
             pkg.Engine.step_group(es, 20, 0.58, 0.06)
             assert all(e.info().steps_done == 20 and e.get_option("agree_checks") >= 1 for e in es)

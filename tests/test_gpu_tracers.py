@@ -232,3 +232,29 @@ def test_frame_loop_with_the_device_canvas_is_interactive(pkg):
             wt.frame(render=False); tr.draw(layer, 16.0); img = wt.compose_frame(trails=layer)
         fps = 60 / (time.perf_counter() - t0)
         assert img.shape == (360, 680, 4) and fps > 60, fps
+
+
+def test_canvas_at_another_scale_neither_wipes_live_trails_nor_loses_the_labels(pkg):
+    """A handle holds one canvas at one scale: composing at another scale while tracer strokes live on the particle layer is REFUSED
+    (it used to free the layer silently); once the layer is cleared the canvas may change scale, and the labels are uploaded again for the new
+    canvas although the host object remembers having sent them for the old one."""
+    from airfoil_cfd_tool_amd import compose
+    with pkg.WindTunnel(shape="naca2412", nx=320, ny=160, aoa_deg=6.0) as wt:
+        layer, tr = wt.trail_layer(2), pkg.Tracers(wt, n=300, seed=5)
+        for _ in range(4):
+            wt.frame(render=False)
+            tr.draw(layer, 16.0)
+        with_trails = wt.compose_frame(trails=layer, scale=2)
+        assert wt.engine.get_option("canvas_layer_live") == 1.0 and wt.engine.get_option("canvas_scale") == 2.0
+        with pytest.raises(pkg.WTError) as ei:
+            wt.compose_frame(scale=1)                                     # would re-allocate the canvas and wipe the scale-2 layer
+        assert ei.value.code == -5 and "wipe" in str(ei.value)
+        again = wt.compose_frame(trails=layer, scale=2)                   # the trails are still there
+        assert np.array_equal(again, with_trails)
+        wt.engine.canvas_stroke(2, 2)                                     # clear the layer: the canvas may now change scale
+        small = wt.compose_frame(scale=1)
+        ref = compose.compose(wt.render_rgba()[::-1], wt.geometry.xp, wt.geometry.yp, wt.aoa_deg, 0, wt.y_half_world())
+        assert small.shape == (360, 680, 4) and int(np.abs(small.astype(int) - ref.astype(int)).max()) <= 1      # labels included
+        big = wt.compose_frame(scale=2)                                   # back to scale 2: same (scale, field, angle) key as the first frames,
+        ref2 = compose.compose(wt.render_rgba()[::-1], wt.geometry.xp, wt.geometry.yp, wt.aoa_deg, 0, wt.y_half_world(), scale=2)
+        assert int(np.abs(big.astype(int) - ref2.astype(int)).max()) <= 1  # yet the labels are there: the new canvas had none and got them again
