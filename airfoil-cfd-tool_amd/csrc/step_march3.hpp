@@ -169,7 +169,7 @@ __device__ __forceinline__ void site_step1_seams(const T *__restrict__ rec, cons
 template <typename T, int S, int FD, int DEPTH>
 __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
                                                 const uint8_t *__restrict__ bcode, const uint8_t *__restrict__ flags, T *__restrict__ hl, const Geom &g, int nwin, int use_seams,
-                                                const FastDiv &fdv, T tau, T U0)
+                                                const FastDiv &fdv, T tau, T U0, int xb0, int nbx)
 {
     constexpr int WIN = 64 * S, NL = DEPTH - 1;
     constexpr int C1 = HL_COLS + 2 * NL, R1 = 2 * NL;                  // level 1: columns x0 - NL + c1, rows WIN b - NL + r
@@ -181,9 +181,10 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
     // the 60 lines are put together in l1's memory once nobody reads it any more (behind the third barrier): fp64 stays at three workgroups per CU
     static_assert(sizeof(T) * C1 * R1 * PADK >= sizeof(T) * HL_COLS * M3_HL, "the lines fit into l1");
     T (*ol)[M3_HL] = reinterpret_cast<T (*)[M3_HL]>(&l1[0][0][0]);
-    const int nblk_x = (g.nxl + HL_COLS - 1) / HL_COLS;
-    const int b = 1 + (int)(blockIdx.x / nblk_x);
-    const int x0 = (int)(blockIdx.x % nblk_x) * HL_COLS;
+    // the launch covers the column blocks xb0 .. xb0 + nbx - 1 of every seam (a whole pass: all of them; the edge strips of a slab's fused
+    // renewal: the blocks that hold its refreshed ghost columns, windtunnel.hip renew_fused)
+    const int b = 1 + (int)(blockIdx.x / nbx);
+    const int x0 = (xb0 + (int)(blockIdx.x % nbx)) * HL_COLS;
     const uint8_t *m = mask + g.pitch;
     const T *s = fs + g.pitch;                                          // column 0 of the lattice
     typedef T t4 __attribute__((ext_vector_type(4)));
@@ -343,16 +344,16 @@ __device__ __forceinline__ void halo_lines_body(const T *__restrict__ fs, const 
 template <typename T, int S, int FD>
 __global__ __launch_bounds__(256) void k_halo3(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
                                                const uint8_t *__restrict__ bcode, const uint8_t *__restrict__ flags3, T *__restrict__ hl, Geom g, int nwin, int use_seams,
-                                               FastDiv fdv, T tau, T U0)
+                                               FastDiv fdv, T tau, T U0, int xb0, int nbx)
 {
-    halo_lines_body<T, S, FD, 3>(fs, seams3, mask, bcode, flags3, hl, g, nwin, use_seams, fdv, tau, U0);
+    halo_lines_body<T, S, FD, 3>(fs, seams3, mask, bcode, flags3, hl, g, nwin, use_seams, fdv, tau, U0, xb0, nbx);
 }
 template <typename T, int S, int FD>
 __global__ __launch_bounds__(256) void k_halo4(const T *__restrict__ fs, const T *__restrict__ seams3, const uint8_t *__restrict__ mask,
                                                const uint8_t *__restrict__ bcode, const uint8_t *__restrict__ flags4, T *__restrict__ hl, Geom g, int nwin, int use_seams,
-                                               FastDiv fdv, T tau, T U0)
+                                               FastDiv fdv, T tau, T U0, int xb0, int nbx)
 {
-    halo_lines_body<T, S, FD, 4>(fs, seams3, mask, bcode, flags4, hl, g, nwin, use_seams, fdv, tau, U0);
+    halo_lines_body<T, S, FD, 4>(fs, seams3, mask, bcode, flags4, hl, g, nwin, use_seams, fdv, tau, U0, xb0, nbx);
 }
 
 // ------------------------------------------------------------------------------------------------

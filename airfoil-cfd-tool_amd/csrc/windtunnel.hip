@@ -188,6 +188,10 @@ struct wt_handle {
     // the pass" (the kept plan's range shrunk at the slab's local edges), cut lazily with the kept plan's measured column costs.
     struct TrimPlan { int v_after = -1; MarchUnit *d_units = nullptr; size_t cap = 0; int n_units = 0; bool valid = false; };
     std::vector<TrimPlan> trim_plans;
+    // refresh = 2 (renew_plan_for): per pass length, the unit lists of the interior columns [0] and of the two edge strips [1]
+    struct RenewPlan { int depth = 0; MarchUnit *d_units[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}; int n_units[2] = {0, 0}; int strip_lo[2] = {0, 0}, strip_hi[2] = {0, 0}; bool valid = false; };
+    std::vector<RenewPlan> renew_plans;
+    long long fused_renewals = 0;        // ghost renewals taken inside a fused pass (option "fused_renewals")
     std::vector<float> colw_kept;        // column-cost corrections of the plan tune_fuse_plan kept (empty: the modelled costs)
     bool trim = true;                    // option "trim_ghosts"
     int refresh_mode = 0;                // option "refresh": 0 = a single step with the exchange beside its interior columns, 1 = the exchange at a
@@ -406,6 +410,7 @@ extern "C" int wt_destroy(wt_handle *h)
     if (h->seam_plain) (void)hipFree(h->seam_plain);
     if (h->d_units) (void)hipFree(h->d_units);
     for (auto &tp : h->trim_plans) if (tp.d_units) (void)hipFree(tp.d_units);
+    for (auto &rp : h->renew_plans) for (int i = 0; i < 2; i++) if (rp.d_units[i]) (void)hipFree(rp.d_units[i]);
     if (h->d_clk) (void)hipFree(h->d_clk);
     if (h->d_nbad) (void)hipFree(h->d_nbad);
     if (h->d_agree) (void)hipFree(h->d_agree);
@@ -571,6 +576,7 @@ static int upload_units(wt_handle *h, const MarchPlan &plan_in)
                 if (pl.units[b].flags & MU_CHAIN) { pl.units[b + 1].flags = 0; break; }
     }
     for (auto &tp : h->trim_plans) tp.valid = false;       // cut from the kept plan's costs: stale now
+    for (auto &rp : h->renew_plans) rp.valid = false;
     h->n_chain_units = 0;
     for (const MarchUnit &u : pl.units) h->n_chain_units += (u.flags & MU_CHAIN) != 0;
     const size_t total = pl.units.size();
@@ -898,7 +904,8 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         return WT_OK;
     }
     if (strcmp(name, "refresh") == 0) {
-        if (!(value == 0.0 || value == 1.0)) return fail(WT_ERR_ARG, "refresh must be 0 (overlapped single step) or 1 (exchange at a pass boundary)");
+        if (!(value == 0.0 || value == 1.0 || value == 2.0))
+            return fail(WT_ERR_ARG, "refresh must be 0 (overlapped single step), 1 (exchange at a pass boundary) or 2 (exchange beside the interior of a fused pass)");
         h->refresh_mode = (int)value;
         return WT_OK;
     }
@@ -933,6 +940,7 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "passes") == 0) { *value = (double)h->passes; return WT_OK; }
     if (strcmp(name, "trim_ghosts") == 0) { *value = h->trim ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "refresh") == 0) { *value = h->refresh_mode; return WT_OK; }
+    if (strcmp(name, "fused_renewals") == 0) { *value = (double)h->fused_renewals; return WT_OK; }
     if (strcmp(name, "boundary_exchanges") == 0) { *value = (double)h->boundary_exchanges; return WT_OK; }
     if (strcmp(name, "trimmed_passes") == 0) { *value = (double)h->trimmed_passes; return WT_OK; }
     if (strcmp(name, "pass_depth") == 0) { *value = h->fuse_ready ? eff_depth(h) : 0; return WT_OK; }       // steps a full pass takes for the tau of the last stepping call
@@ -1417,13 +1425,11 @@ static int trim_plan_for(wt_handle *h, int v_after, const MarchUnit **units, int
     return WT_OK;
 }
 
-// Three steps in one pass (step_march3.hpp), or two on the same tables (depth = 2: what a step count leaves over).
-// A = f[cur] (time t), B = f[1-cur] (receives time t + depth).
-template <typename T, int S, int FD>
-static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, int depth, bool two_op = false)
+// ---- one pass of k_march3 (step_march3.hpp): the parameter block, the halo-line kernel over a range of column blocks, the marching kernel ----
+template <typename T>
+static void march3_params(wt_handle *h, double tau, double u0, MarchParams<T> &p)
 {
     const Geom &g = h->g;
-    MarchParams<T> p;
     p.fs = fptr<T>(h, h->cur);
     p.fd = fptr<T>(h, 1 - h->cur);
     p.macro = reinterpret_cast<T *>(h->macro);
@@ -1438,24 +1444,71 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     p.U0 = (T)u0;
     p.rev = (int)(h->passes & 1);
     p.stuck = h->stuck_dev;
+    p.units = h->d_units; p.nunits = h->n_units;
+}
+
+// level-0 .. level-(D-1) values of the rows around the window seams for the column blocks xb0 .. xb0 + nbx - 1 (HL_COLS columns each; nbx < 0: all)
+template <typename T, int S, int FD>
+static void launch_halo_lines(wt_handle *h, const MarchParams<T> &p, int use_seams, int xb0, int nbx, hipStream_t st)
+{
+    const Geom &g = h->g;
+    if (h->n_win <= 1) return;
+    const int all = (g.nxl + HL_COLS - 1) / HL_COLS;
+    if (nbx < 0) { xb0 = 0; nbx = all; }
+    if (xb0 < 0) { nbx += xb0; xb0 = 0; }
+    if (xb0 + nbx > all) nbx = all - xb0;
+    if (nbx <= 0) return;
+    const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)nbx;
+    if (h->march_depth == 4)        // the plan's tables are those of the four-step pass, whatever this pass advances
+        hipLaunchKernelGGL((k_halo4<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
+                           (const uint8_t *)h->seam_plain, reinterpret_cast<T *>(h->hlines), g, h->n_win, use_seams, p.fdv, p.tau, p.U0, xb0, nbx);
+    else
+        hipLaunchKernelGGL((k_halo3<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
+                           (const uint8_t *)h->seam_plain, reinterpret_cast<T *>(h->hlines), g, h->n_win, use_seams, p.fdv, p.tau, p.U0, xb0, nbx);
+}
+
+// the marching kernel over p.units (depth = steps this pass advances, on the tables of h->march_depth)
+template <typename T, int S, int FD>
+static int launch_march3(const MarchParams<T> &p, int depth, bool emit, bool two_op, hipStream_t st)
+{
+    if (p.nunits <= 0) return WT_OK;
+    const dim3 grid((unsigned)((p.nunits + 3) / 4));
+    if (depth == 4) {
+        // (fp32 with the IEEE division by tau: not built — 40-80 bytes of scratch per lane; set_tau_cap keeps such a call at three steps per pass)
+        if constexpr (sizeof(T) == 4 && FD == 0) return fail(WT_ERR_STATE, "internal: four-step pass with the IEEE division");
+        else if constexpr (sizeof(T) == 4 && FD == 1) {
+            // the division by tau in two operations where the device has proved it for this tau (fastdiv_for), in three otherwise
+            if (two_op) {
+                if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD | MARCH_FD_TWOOP>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD | MARCH_FD_TWOOP>), grid, dim3(256), 0, st, p);
+            } else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
+        }
+        else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
+    } else if (depth == 3) {
+        if (emit) hipLaunchKernelGGL((k_march3<T, S, 3, true, FD>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_march3<T, S, 3, false, FD>), grid, dim3(256), 0, st, p);
+    } else {
+        if (emit) hipLaunchKernelGGL((k_march3<T, S, 2, true, FD>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_march3<T, S, 2, false, FD>), grid, dim3(256), 0, st, p);
+    }
+    return WT_OK;
+}
+
+// Three steps in one pass (step_march3.hpp), or two on the same tables (depth = 2: what a step count leaves over).
+// A = f[cur] (time t), B = f[1-cur] (receives time t + depth).
+template <typename T, int S, int FD>
+static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, int depth, bool two_op = false)
+{
+    MarchParams<T> p;
+    march3_params<T>(h, tau, u0, p);
     if (h->clk_on) p.clk = h->d_clk + h->clk_off;
 #ifdef WT_UNIT_CLOCKS         // diagnostic build (tools/unit_clocks.py): every pass records its units
     else { WT_TRY(ensure_clocks(h)); p.clk = h->d_clk; }
 #endif
     hipStream_t st = h->s_compute;
-    if (h->n_win > 1) {        // level-1 and level-2 values of the rows around the window seams
-        if (h->march_depth == 4) {      // the plan's tables are those of the four-step pass, whatever this pass advances
-            const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H4_COLS - 1) / H4_COLS);
-            hipLaunchKernelGGL((k_halo4<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->bcode, (const uint8_t *)h->seam_plain,
-                               reinterpret_cast<T *>(h->hlines), g, h->n_win,
-                               h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
-        } else {
-            const unsigned nblk = (unsigned)(h->n_win - 1) * (unsigned)((g.nxl + H3_COLS - 1) / H3_COLS);
-            hipLaunchKernelGGL((k_halo3<T, S, FD>), dim3(nblk), dim3(256), 0, st, p.fs, (const T *)p.seams, (const uint8_t *)h->mask, (const uint8_t *)h->bcode, (const uint8_t *)h->seam_plain,
-                               reinterpret_cast<T *>(h->hlines), g, h->n_win, h->seams_valid ? 1 : 0, p.fdv, p.tau, p.U0);
-        }
-    }
-    p.units = h->d_units; p.nunits = h->n_units;
+    launch_halo_lines<T, S, FD>(h, p, h->seams_valid ? 1 : 0, 0, -1, st);
     if (h->nranks > 1 && h->trim && !h->clk_on) {
         // ghost columns that will still be exact after this pass: the others are not marched (trim_plan_for)
         const int v_full = h->halo - (h->march_depth - 1), v_after = std::max(0, std::min(h->ghost_valid - depth, v_full));
@@ -1467,29 +1520,7 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
         }
     }
     if (h->clk_on) HIP_TRY(hipEventRecord(h->ev_t0, st));       // tuning passes: the marching kernel alone is timed
-    if (p.nunits > 0) {
-        const dim3 grid((unsigned)((p.nunits + 3) / 4));
-        if (depth == 4) {
-            // (fp32 with the IEEE division by tau: not built — 40-80 bytes of scratch per lane; set_tau_cap keeps such a call at three steps per pass)
-            if constexpr (sizeof(T) == 4 && FD == 0) return fail(WT_ERR_STATE, "internal: four-step pass with the IEEE division");
-            else if constexpr (sizeof(T) == 4 && FD == 1) {
-                // the division by tau in two operations where the device has proved it for this tau (fastdiv_for), in three otherwise
-                if (two_op) {
-                    if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD | MARCH_FD_TWOOP>), grid, dim3(256), 0, st, p);
-                    else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD | MARCH_FD_TWOOP>), grid, dim3(256), 0, st, p);
-                } else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
-                else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
-            }
-            else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
-        } else if (depth == 3) {
-            if (emit) hipLaunchKernelGGL((k_march3<T, S, 3, true, FD>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_march3<T, S, 3, false, FD>), grid, dim3(256), 0, st, p);
-        } else {
-            if (emit) hipLaunchKernelGGL((k_march3<T, S, 2, true, FD>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_march3<T, S, 2, false, FD>), grid, dim3(256), 0, st, p);
-        }
-    }
+    WT_TRY((launch_march3<T, S, FD>(p, depth, emit, two_op, st)));
     HIP_TRY(hipGetLastError());
     if (h->clk_on) HIP_TRY(hipEventRecord(h->ev_t1, st));
     h->cur = 1 - h->cur;
@@ -1501,6 +1532,123 @@ static int step_triple_fused_t(wt_handle *h, double tau, double u0, bool emit, i
     // unwritten whatever the pass advances (march_range3), so a SHORTER pass on those tables still costs D-1 columns of the fresh ghosts
     // (found by the mixed-depth group test: two-step passes on four-step tables right after an initialisation).
     if (h->nranks > 1) h->ghost_valid = std::max(0, std::min(h->ghost_valid - depth, h->halo - (h->march_depth - 1)));
+    return WT_OK;
+}
+
+// ---- refresh = 2: the ghost columns are renewed INSIDE a fused pass ----
+// The exchange (comm stream) runs beside the marching of the INTERIOR columns — those whose `depth`-step cone stays inside the owned columns,
+// [gl + depth, gl + width - depth) —, the two EDGE STRIPS — [gl - (halo - depth), gl + depth) and its mirror image: the owned columns next to
+// the edges and the ghost columns that are still exact after the pass — are marched once the ghosts have landed.  No step of the cycle is a
+// single k_step, no exchange stands alone at a pass boundary, and the seam buffer is never stale for the owned columns: only the strips'
+// halo lines are built by the gather path (their ghost columns are new to this rank).  Two unit lists per pass length, cut with the kept
+// plan's column costs like the trimmed lists.
+static int renew_plan_for(wt_handle *h, int depth, wt_handle::RenewPlan **out)
+{
+    wt_handle::RenewPlan *rp = nullptr;
+    for (auto &t : h->renew_plans) if (t.depth == depth) rp = &t;
+    if (!rp) { h->renew_plans.emplace_back(); rp = &h->renew_plans.back(); rp->depth = depth; }
+    if (!rp->valid) {
+        const Geom &g = h->g;
+        const MarchRange full = march_range3(g, h->march_depth);
+        const int v_after = std::max(0, std::min(h->halo - depth, h->halo - (h->march_depth - 1)));
+        MarchRange ri = full;                                  // interior
+        if (h->gl) ri.i_begin = h->gl + depth;
+        if (h->gr) ri.i_end = h->gl + h->width - depth;
+        if (h->gr) ri.outlet_after = 0;
+        if (ri.i_end - ri.i_begin < 2 * h->march_depth + 2) return fail(WT_ERR_STATE, "slab too narrow for a fused renewal (refresh = 2): %d interior columns", ri.i_end - ri.i_begin);
+        const int max_solo = (h->march_depth == 4 ? MARCH3_MAX_CHUNK - 3 : MARCH3_MAX_CHUNK) - 2;
+        const float *colw = h->colw_kept.empty() ? nullptr : h->colw_kept.data();
+        std::vector<MarchUnit> lists[2];
+        {
+            MarchPlan pl;
+            cut_units(h, colw, &pl, &ri);
+            if (!h->host_wcls.empty()) h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), g, h->march_depth, max_solo);
+            lists[0] = pl.units;
+        }
+        // the strips: a handful of columns per window — units of about (strip / 4) columns, so that a plain strip is one chain block per window
+        const long target_save = h->plan_target;
+        for (int side = 0; side < 2; side++) {
+            if (!(side ? h->gr : h->gl)) continue;
+            MarchRange rs = full;
+            rs.outlet_after = 0;
+            if (side == 0) { rs.i_begin = std::max(full.i_begin, h->gl - v_after); rs.i_end = h->gl + depth; }
+            else { rs.i_begin = h->gl + h->width - depth; rs.i_end = std::min(full.i_end, h->gl + h->width + v_after); }
+            if (rs.i_end <= rs.i_begin) continue;
+            h->plan_target = (long)h->n_win * 4;
+            MarchPlan pl;
+            cut_units(h, colw, &pl, &rs);
+            h->plan_target = target_save;
+            if (!h->host_wcls.empty()) h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), g, h->march_depth, max_solo);
+            lists[1].insert(lists[1].end(), pl.units.begin(), pl.units.end());
+        }
+        h->plan_target = target_save;
+        while (lists[1].size() % 4) lists[1].push_back(MarchUnit{0, 0, 0, 0});
+        for (int i = 0; i < 2; i++) {
+            const size_t total = lists[i].size();
+            if (total > rp->cap[i]) {
+                if (rp->d_units[i]) { HIP_TRY(hipFree(rp->d_units[i])); rp->d_units[i] = nullptr; rp->cap[i] = 0; }
+                const size_t cap = total + total / 4 + 64;
+                HIP_TRY(hipMalloc((void **)&rp->d_units[i], cap * sizeof(MarchUnit)));
+                rp->cap[i] = cap;
+            }
+            if (total > 0) HIP_TRY(hipMemcpyAsync(rp->d_units[i], lists[i].data(), total * sizeof(MarchUnit), hipMemcpyHostToDevice, h->s_compute));
+            rp->n_units[i] = (int)total;
+        }
+        HIP_TRY(hipStreamSynchronize(h->s_compute));
+        rp->strip_lo[0] = std::max(full.i_begin, h->gl - v_after); rp->strip_hi[0] = h->gl + depth;
+        rp->strip_lo[1] = h->gl + h->width - depth; rp->strip_hi[1] = std::min(full.i_end, h->gl + h->width + v_after);
+        rp->valid = true;
+    }
+    *out = rp;
+    return WT_OK;
+}
+
+// The interior half: to be enqueued right after halo_begin(h) (the exchange is then on its way on the comm stream).
+template <typename T, int S, int FD>
+static int renew_interior_t(wt_handle *h, double tau, double u0, bool emit, int depth, bool two_op, bool seams_were_valid)
+{
+    wt_handle::RenewPlan *rp = nullptr;
+    WT_TRY(renew_plan_for(h, depth, &rp));
+    MarchParams<T> p;
+    march3_params<T>(h, tau, u0, p);
+    hipStream_t st = h->s_compute;
+    if (h->xt_on) HIP_TRY(hipEventRecord(xt_event(h, 2), st));
+    launch_halo_lines<T, S, FD>(h, p, seams_were_valid ? 1 : 0, 0, -1, st);      // (the lines of the ghost columns come out of stale records: rebuilt below, unused here)
+    p.units = rp->d_units[0]; p.nunits = rp->n_units[0];
+    WT_TRY((launch_march3<T, S, FD>(p, depth, emit, two_op, st)));
+    HIP_TRY(hipGetLastError());
+    if (h->xt_on) HIP_TRY(hipEventRecord(xt_event(h, 3), st));
+    return WT_OK;
+}
+// The edge strips: after the compute stream has waited for the exchange.
+template <typename T, int S, int FD>
+static int renew_strips_t(wt_handle *h, double tau, double u0, bool emit, int depth, bool two_op)
+{
+    wt_handle::RenewPlan *rp = nullptr;
+    WT_TRY(renew_plan_for(h, depth, &rp));
+    MarchParams<T> p;
+    march3_params<T>(h, tau, u0, p);
+    hipStream_t st = h->s_compute;
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_halo, 0));
+    if (h->xt_on) { HIP_TRY(hipEventRecord(xt_event(h, 4), st)); h->xt_n += 1; }
+    // halo lines of the strips' columns from the lattice (gather path): every line a strip unit reads lies within march_depth columns of its range
+    const int D = h->march_depth;
+    for (int side = 0; side < 2; side++) {
+        if (!(side ? h->gr : h->gl) || rp->strip_hi[side] <= rp->strip_lo[side]) continue;
+        const int lo = std::max(0, rp->strip_lo[side] - D), hi = std::min(h->g.nxl, rp->strip_hi[side] + D);
+        launch_halo_lines<T, S, FD>(h, p, 0, lo / HL_COLS, (hi - 1) / HL_COLS - lo / HL_COLS + 1, st);
+    }
+    p.units = rp->d_units[1]; p.nunits = rp->n_units[1];
+    p.rev = 0;
+    WT_TRY((launch_march3<T, S, FD>(p, depth, emit, two_op, st)));
+    HIP_TRY(hipGetLastError());
+    h->cur = 1 - h->cur;
+    h->steps_done += depth;
+    h->passes += 1;
+    h->passes_total += 1;
+    h->seams_valid = true;                       // interior and strips together wrote the seam rows of every column that is still exact
+    h->ghost_valid = std::max(0, std::min(h->halo - depth, h->halo - (h->march_depth - 1)));
+    h->fused_renewals += 1;
     return WT_OK;
 }
 
@@ -1535,6 +1683,31 @@ static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
         return fd ? step_triple_fused_t<float, 2, 1>(h, tau, u0, emit, k, fd2) : step_triple_fused_t<float, 2, 0>(h, tau, u0, emit, k);
     }
     return step_pair_fused(h, tau, u0, emit);
+}
+
+// refresh = 2: is the next thing a slab does a fused renewal — a pass of k > 0 steps with the exchange beside its interior columns?
+// Due when a fused pass is wanted (at least two steps to go) and fewer than two exact ghost columns are left for it.
+static inline int renew_stride(const wt_handle *h, int left)
+{
+    if (!(h->nranks > 1 && h->refresh_mode == 2 && h->fuse_ready && h->march_depth >= 3) || left < 2 || h->ghost_valid >= 2) return 0;
+    return fuse_pick(eff_depth(h), std::min(left, h->halo));
+}
+// the two halves of such a pass (see renew_interior_t): between them every slab's exchange is in flight
+static int renew_interior(wt_handle *h, double tau, double u0, bool emit, int k, bool seams_were_valid)
+{
+    if (h->dtype != WT_F32) return renew_interior_t<double, 1, 1>(h, tau, u0, emit, k, false, seams_were_valid);
+    if (h->fast_math) return renew_interior_t<float, 2, MARCH_FD_CONTRACTED>(h, tau, u0, emit, k, false, seams_were_valid);
+    bool fd = false, fd2 = false;
+    WT_TRY(fastdiv_for(h, (float)tau, &fd, &fd2));
+    return fd ? renew_interior_t<float, 2, 1>(h, tau, u0, emit, k, fd2, seams_were_valid) : renew_interior_t<float, 2, 0>(h, tau, u0, emit, k, false, seams_were_valid);
+}
+static int renew_strips(wt_handle *h, double tau, double u0, bool emit, int k)
+{
+    if (h->dtype != WT_F32) return renew_strips_t<double, 1, 1>(h, tau, u0, emit, k, false);
+    if (h->fast_math) return renew_strips_t<float, 2, MARCH_FD_CONTRACTED>(h, tau, u0, emit, k, false);
+    bool fd = false, fd2 = false;
+    WT_TRY(fastdiv_for(h, (float)tau, &fd, &fd2));
+    return fd ? renew_strips_t<float, 2, 1>(h, tau, u0, emit, k, fd2) : renew_strips_t<float, 2, 0>(h, tau, u0, emit, k, false);
 }
 
 // Measure, then cut again.  The cut by time rests on a model of what a column costs (cut_units), and a launch takes as long as its
@@ -1809,6 +1982,15 @@ static int run_steps(wt_handle *h, int nsteps, double tau, double u0)
             if (h->transport == TR_NONE) return fail(WT_ERR_STATE, "slab handle has no transport (wt_comm_init_rank / wt_link_local)");
             WT_TRY(exchange_at_boundary(h));
         }
+        if (const int kr = renew_stride(h, nsteps - s)) {         // refresh = 2: exchange || interior columns, then the edge strips
+            if (h->transport == TR_NONE) return fail(WT_ERR_STATE, "slab handle has no transport (wt_comm_init_rank / wt_link_local)");
+            const bool sv = h->seams_valid;
+            WT_TRY(halo_begin(h));
+            WT_TRY(renew_interior(h, tau, u0, s + kr == nsteps, kr, sv));
+            WT_TRY(renew_strips(h, tau, u0, s + kr == nsteps, kr));
+            s += kr;
+            continue;
+        }
         const int k = fuse_stride(h, nsteps - s);
         if (k > 0) {
             WT_TRY(step_fused(h, tau, u0, s + k == nsteps, k));
@@ -1838,6 +2020,13 @@ extern "C" int wt_plan_steps(wt_handle *h, int nsteps, double tau, int *seq, int
             if (n < cap) seq[n] = -2;
             n++;
             h->ghost_valid = h->halo;
+        }
+        if (const int kr = renew_stride(h, nsteps - s)) {     // refresh = 2: 100 + k = a fused pass of k steps that renews the ghost columns
+            if (n < cap) seq[n] = 100 + kr;
+            n++;
+            h->ghost_valid = std::max(0, std::min(h->halo - kr, h->halo - (h->march_depth - 1)));
+            s += kr;
+            continue;
         }
         const int k = fuse_stride(h, nsteps - s);
         int code;
@@ -2049,6 +2238,36 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
                 HIP_TRY(hipSetDevice(hs[r]->device));
                 if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_l->ev_halo, 0));
                 if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_r->ev_halo, 0));
+            }
+        }
+        // refresh = 2 (agreed by the group): the renewal inside a fused pass — every exchange is enqueued, then every slab marches its interior
+        // columns beside it, then the edge strips once its own ghosts have landed
+        {
+            int kr = 1 << 30;
+            for (int r = 0; r < n && n > 1; r++) kr = std::min(kr, renew_stride(hs[r], nsteps - s));
+            if (n > 1 && kr > 0 && kr < (1 << 30)) {
+                std::vector<char> sv((size_t)n);
+                for (int r = 0; r < n; r++) {
+                    HIP_TRY(hipSetDevice(hs[r]->device));
+                    HIP_TRY(hipEventRecord(hs[r]->ev_state, hs[r]->s_compute));
+                    sv[(size_t)r] = hs[r]->seams_valid ? 1 : 0;
+                }
+                for (int r = 0; r < n; r++) {
+                    HIP_TRY(hipSetDevice(hs[r]->device));
+                    if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_comm, hs[r]->peer_l->ev_state, 0));
+                    if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_comm, hs[r]->peer_r->ev_state, 0));
+                }
+                for (int r = 0; r < n; r++) { HIP_TRY(hipSetDevice(hs[r]->device)); WT_TRY(halo_begin(hs[r])); }
+                const bool emit_r = s + kr == nsteps;
+                for (int r = 0; r < n; r++) { HIP_TRY(hipSetDevice(hs[r]->device)); WT_TRY(renew_interior(hs[r], tau, u0, emit_r, kr, sv[(size_t)r] != 0)); }
+                for (int r = 0; r < n; r++) { HIP_TRY(hipSetDevice(hs[r]->device)); WT_TRY(renew_strips(hs[r], tau, u0, emit_r, kr)); }
+                for (int r = 0; r < n; r++) {                  // a peer's NEXT pass overwrites the lattice my copies read: it waits for them
+                    HIP_TRY(hipSetDevice(hs[r]->device));
+                    if (hs[r]->peer_l) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_l->ev_halo, 0));
+                    if (hs[r]->peer_r) HIP_TRY(hipStreamWaitEvent(hs[r]->s_compute, hs[r]->peer_r->ev_halo, 0));
+                }
+                s += kr;
+                continue;
             }
         }
         // one pass length for the whole group: the shortest plan depth and the fewest exact ghost columns of any slab (edge

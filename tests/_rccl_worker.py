@@ -30,11 +30,14 @@ def main():
     mask = pkg.geometry.build_geometry(nx, ny, 9.0, None, "naca4412").mask
     ok = True
     uneven = [0] + [int(nx * (0.30 + 0.40 * k / (world - 1))) for k in range(world - 1)] + [nx]     # slabs cut by the caller (wt_create_slab_at)
-    for dtype, depth, edges in (("float32", 0, None), ("float32", 2, None), ("float64", 0, None), ("float32", 0, uneven)):
+    # (refresh 2: the ghost columns renewed inside a fused pass — the exchange beside its interior columns, over the transport under test)
+    for dtype, depth, edges, refresh in (("float32", 0, None, 0), ("float32", 2, None, 0), ("float64", 0, None, 0), ("float32", 0, uneven, 0),
+                                         ("float32", 0, None, 2), ("float64", 0, uneven, 2)):
         eng = pkg.Engine(nx, ny, dtype=dtype, device=local, rank=rank, nranks=world, halo=halo, edges=edges)
         if depth:
             eng.set_option("fuse_depth", depth)
         eng.set_option("fuse_steps", 2)
+        eng.set_option("refresh", refresh)
         ids = [pkg.Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         eng.comm_init_rank(ids[0])                          # (all-reduces the schedule fingerprint: a rank that would plan differently fails here)
@@ -50,6 +53,9 @@ def main():
             break
         for n in chunks:
             eng.step(n, 0.58, 0.06)
+        if refresh == 2 and eng.get_option("fuse_depth") >= 3 and (eng.get_option("fused_renewals") < 1 or eng.get_option("boundary_exchanges") != 0):
+            print(f"rank {rank}: refresh 2 took no fused renewal", flush=True)
+            ok = False
         f = eng.read_f()                                    # this rank's owned columns
         rho, ux, uy = eng.read_macro()
         gathered = [None] * world
@@ -66,7 +72,7 @@ def main():
             same = (np.array_equal(fa.view(np.uint8), fr.view(np.uint8))
                     and all(np.array_equal(np.concatenate([g[i] for g in gathered], axis=1).view(np.uint8), m.view(np.uint8))
                             for i, m in ((1, r0), (2, u0), (3, v0))))
-            print(f"rccl slabs {dtype} depth={depth or 'auto'} world={world} edges={edges or 'equal'}: {'PASS' if same else 'FAIL'}", flush=True)
+            print(f"rccl slabs {dtype} depth={depth or 'auto'} world={world} edges={edges or 'equal'} refresh={refresh}: {'PASS' if same else 'FAIL'}", flush=True)
             ok &= bool(same)
     # a rank with another knob value is refused by EVERY rank inside wt_comm_init_rank — an error, not a hang at the first exchange
     eng = pkg.Engine(nx, ny, device=local, rank=rank, nranks=world, halo=halo)

@@ -25,4 +25,4 @@ def test_rccl_slabs_equal_single_lattice(world, halo):
            "--master-port", str(29650 + world + halo), os.path.join(HERE, "_rccl_worker.py"), str(halo)]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert r.stdout.count("PASS") == 5 and "FAIL" not in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("PASS") == 7 and "FAIL" not in r.stdout, r.stdout[-3000:]

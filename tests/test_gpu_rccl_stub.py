@@ -38,7 +38,7 @@ def test_slab_ranks_over_the_stand_in_transport_equal_single_lattice(stub, world
            "--master-port", str(29700 + world + halo), os.path.join(HERE, "_rccl_worker.py"), str(halo)]
     r = subprocess.run(cmd, env=_env(stub), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:]
-    assert r.stdout.count("PASS") == 5 and "FAIL" not in r.stdout, r.stdout[-4000:]
+    assert r.stdout.count("PASS") == 7 and "FAIL" not in r.stdout, r.stdout[-4000:]
 
 
 def test_bench_two_ranks_end_to_end_over_the_stand_in_transport(stub):

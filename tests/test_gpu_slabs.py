@@ -447,3 +447,72 @@ def test_all_fused_refresh_cycle_equals_single_lattice(pkg, dtype, nranks, halo)
     finally:
         for e in es:
             e.close()
+
+
+@pytest.mark.parametrize("dtype,nranks,halo,shape,aoa", [("float32", 4, 17, "naca2412", 7.0), ("float32", 2, 29, "naca6409", 10.0), ("float64", 3, 13, "naca2412", 7.0),
+                                                         ("float32", 3, 28, "naca0012", 8.0)])
+def test_fused_renewal_cycle_equals_single_lattice(pkg, dtype, nranks, halo, shape, aoa):
+    """option refresh = 2: the ghost columns are renewed INSIDE a fused pass — the exchange runs beside the marching of the
+    interior columns, the edge strips follow once the ghosts have landed.  Through more than three refresh cycles no step is a single k_step
+    (`single_steps` 0), no exchange stands alone at a pass boundary (`boundary_exchanges` 0), the planned schedule (100 + k = a renewing pass of k
+    steps) is the one that runs, and owned columns and (rho, ux, uy) equal the single lattice bit for bit (STEP_FS html:283-360, the split SURVEY 8e)."""
+    nx, ny = 600 * nranks, 1024
+    mask = pkg.geometry.build_geometry(nx, ny, aoa, None, shape).mask
+    chunks = [2 * halo, halo + 8, 40, 4 * halo, 5]
+    f0, m0, _, _ = _single(pkg, mask, chunks, 0.58, 0.06, dtype)
+    es = [pkg.Engine(nx, ny, dtype=dtype, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_option("refresh", 2)
+            e.set_mask(mask); e.init_equilibrium(0.06)
+        assert all(e.get_option("fuse_active") == 1.0 and e.get_option("fuse_depth") >= 3 for e in es)
+        renewals = 0
+        for n in chunks:
+            plan = es[0].plan_steps(n, 0.58)
+            assert all(e.plan_steps(n, 0.58) == plan for e in es)
+            assert all(k >= 2 for k in plan) and sum(k - 100 if k > 100 else k for k in plan) == n          # fused passes only, some of them renewing
+            r0 = [e.get_option("fused_renewals") for e in es]
+            pkg.Engine.step_group(es, n, 0.58, 0.06)
+            assert [e.get_option("fused_renewals") - a for e, a in zip(es, r0)] == [sum(1 for k in plan if k > 100)] * nranks
+            renewals += sum(1 for k in plan if k > 100)
+        assert renewals >= 4
+        assert all(e.get_option("single_steps") == 0 and e.get_option("boundary_exchanges") == 0 for e in es)
+        f1 = np.concatenate([e.read_f() for e in es], axis=2)
+        m1 = [np.concatenate(p, axis=1) for p in zip(*[e.read_macro() for e in es])]
+    finally:
+        for e in es:
+            e.close()
+    assert bits_equal(f0, f1)
+    assert all(bits_equal(a, b) for a, b in zip(m0, m1))
+
+
+def test_fused_renewal_after_write_f_and_with_a_mask_change(pkg):
+    """refresh = 2 from a state whose ghosts are stale from the start (wt_write_f: the first thing a slab does is a renewing pass whose halo lines
+    all come from the lattice) and across a mask upload (the AoA slider: the seam buffer is stale, the renewal plans are cut again)."""
+    nx, ny, nranks, halo = 1800, 512, 3, 16
+    geo = pkg.geometry
+    m_a, m_b = geo.build_geometry(nx, ny, 4.0, None, "naca2412").mask, geo.build_geometry(nx, ny, 9.0, None, "naca2412").mask
+    with pkg.Engine(nx, ny) as ref:
+        ref.set_option("fuse_steps", 0)
+        ref.set_mask(m_a); ref.init_equilibrium(0.06); ref.step(37, 0.58, 0.06)
+        f_mid = ref.read_f()
+        ref.step(50, 0.58, 0.06); ref.set_mask(m_b); ref.step(45, 0.58, 0.06)
+        f_ref = ref.read_f()
+    es = [pkg.Engine(nx, ny, rank=r, nranks=nranks, halo=halo) for r in range(nranks)]
+    try:
+        pkg.Engine.link_local(es)
+        for e in es:
+            e.set_option("refresh", 2); e.set_option("fuse_steps", 2)
+            e.set_mask(m_a); e.init_equilibrium(0.06)
+            e.write_f(np.ascontiguousarray(f_mid[:, :, e.x0:e.x0 + e.width]))
+        pkg.Engine.step_group(es, 50, 0.58, 0.06)
+        for e in es:
+            e.set_mask(m_b)
+        pkg.Engine.step_group(es, 45, 0.58, 0.06)
+        assert all(e.get_option("single_steps") == 0 and e.get_option("fused_renewals") >= 5 for e in es)
+        f1 = np.concatenate([e.read_f() for e in es], axis=2)
+    finally:
+        for e in es:
+            e.close()
+    assert bits_equal(f_ref, f1)
