@@ -11,6 +11,6 @@ from .windtunnel import (WindTunnel, build_lbm_component, Stats, stall_label, ta
                          reynolds, chord_cells, write_png, FIELD_MODES, TAU_DEFAULT, U0_DEFAULT, VORT_SCALE, STEPS_PER_FRAME)
 
 from .tracers import Tracers  # noqa: F401
-from .distributed import SlabWindTunnel, LocalSlabWindTunnel, slab_bounds, slab_edges, balanced_edges, balance_split, balance_over_group, measure_slab_cost  # noqa: F401
+from .distributed import SlabWindTunnel, LocalSlabWindTunnel, slab_bounds, slab_edges, balanced_edges, balance_split, balance_over_group, measure_slab_cost, measure_slab_real  # noqa: F401
 
 __all__ = ["WindTunnel", "build_lbm_component", "Engine", "WTError", "geometry", "load_library"]

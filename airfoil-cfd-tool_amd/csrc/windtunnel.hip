@@ -1565,7 +1565,10 @@ static int renew_plan_for(wt_handle *h, int depth, wt_handle::RenewPlan **out)
             if (!h->host_wcls.empty()) h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), g, h->march_depth, max_solo);
             lists[0] = pl.units;
         }
-        // the strips: a handful of columns per window — units of about (strip / 4) columns, so that a plain strip is one chain block per window
+        // the strips: a handful of columns per window.  They run AFTER the exchange, with nothing beside them: what counts is how long their slowest
+        // unit takes, not how many columns are recomputed — so they are cut by time into as many units as the device holds (a plain strip column
+        // becomes a unit of its own: 1 + the pipeline's fill instead of halo + fill iterations; measured on the 8-way split of 4096^2,
+        // profiles/r05_d_slab_costs_cfg2.txt)
         const long target_save = h->plan_target;
         for (int side = 0; side < 2; side++) {
             if (!(side ? h->gr : h->gl)) continue;
@@ -1574,7 +1577,7 @@ static int renew_plan_for(wt_handle *h, int depth, wt_handle::RenewPlan **out)
             if (side == 0) { rs.i_begin = std::max(full.i_begin, h->gl - v_after); rs.i_end = h->gl + depth; }
             else { rs.i_begin = h->gl + h->width - depth; rs.i_end = std::min(full.i_end, h->gl + h->width + v_after); }
             if (rs.i_end <= rs.i_begin) continue;
-            h->plan_target = (long)h->n_win * 4;
+            h->plan_target = std::max<long>(h->n_win, target_save / ((h->gl ? 1 : 0) + (h->gr ? 1 : 0)));
             MarchPlan pl;
             cut_units(h, colw, &pl, &rs);
             h->plan_target = target_save;
@@ -1686,10 +1689,14 @@ static int step_fused(wt_handle *h, double tau, double u0, bool emit, int k)
 }
 
 // refresh = 2: is the next thing a slab does a fused renewal — a pass of k > 0 steps with the exchange beside its interior columns?
-// Due when a fused pass is wanted (at least two steps to go) and fewer than two exact ghost columns are left for it.
+// Due when a fused pass is wanted (at least two steps to go) and fewer than two exact ghost columns are left for it
+// ... or when the pass the remaining ghost columns allow would leave exactly ONE step behind (3 steps to go on 2 exact ghost columns): a renewal may
+// come early — it renews everything —, and with fresh ghosts the steps to go split into fused passes (3, or 3 + 2 for 5).
 static inline int renew_stride(const wt_handle *h, int left)
 {
-    if (!(h->nranks > 1 && h->refresh_mode == 2 && h->fuse_ready && h->march_depth >= 3) || left < 2 || h->ghost_valid >= 2) return 0;
+    if (!(h->nranks > 1 && h->refresh_mode == 2 && h->fuse_ready && h->march_depth >= 3) || left < 2) return 0;
+    const int k = fuse_pick(eff_depth(h), std::min(left, h->ghost_valid));
+    if (h->ghost_valid >= 2 && k > 0 && left - k != 1) return 0;
     return fuse_pick(eff_depth(h), std::min(left, h->halo));
 }
 // the two halves of such a pass (see renew_interior_t): between them every slab's exchange is in flight
@@ -2161,7 +2168,19 @@ extern "C" int wt_comm_selftest(int device, int ny)
 
 extern "C" int wt_link_local(wt_handle **hs, int n)
 {
-    if (!hs || n < 2) return fail(WT_ERR_ARG, "need at least two slab handles");
+    if (hs && n == 1 && hs[0] && hs[0]->nranks > 1) {
+        // ONE slab handle linked to ITSELF: its ghost columns are refreshed from its own owned edge columns (a tunnel periodic in x over this slab).
+        // The timing stand-in for one slab of a split (distributed.measure_slab_real, tools/r5_slab_costs.py): the whole slab state machine — trimmed
+        // ghost marching, the refresh mode, the exchange beside the interior — runs on one handle alone on the GPU, with a copy kernel as the exchange.
+        wt_handle *h = hs[0];
+        if (h->transport != TR_NONE) return fail(WT_ERR_STATE, "handle already has a transport");
+        if (h->width < 2 * h->halo) return fail(WT_ERR_ARG, "a self-linked slab needs at least 2 x halo owned columns");
+        h->peer_l = h->gl ? h : nullptr;
+        h->peer_r = h->gr ? h : nullptr;
+        h->transport = TR_LOCAL;
+        return WT_OK;
+    }
+    if (!hs || n < 2) return fail(WT_ERR_ARG, "need at least two slab handles (or one slab handle, linked to itself)");
     for (int r = 0; r < n; r++) {
         wt_handle *h = hs[r];
         WT_TRY(check_handle(h));
@@ -2215,11 +2234,12 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
         if (hs[r]->steps_done != hs[0]->steps_done) return fail(WT_ERR_STATE, "slabs are not at the same step");
     }
     WT_TRY(group_prepare(hs, n, nsteps, tau, u0));
+    const bool multi = n > 1 || (hs[0]->nranks > 1 && hs[0]->transport == TR_LOCAL);      // (one handle: a whole tunnel, or a slab linked to itself)
     int s = 0;
     while (s < nsteps) {
         // refresh = 1 (agreed by the group): an exchange at a pass boundary as soon as any slab is short of exact ghost columns
         bool xdue = false;
-        for (int r = 0; r < n && n > 1; r++) xdue = xdue || boundary_exchange_due(hs[r], nsteps - s);
+        for (int r = 0; r < n && multi; r++) xdue = xdue || boundary_exchange_due(hs[r], nsteps - s);
         if (xdue) {
             for (int r = 0; r < n; r++) {                      // every slab's comm stream must see its neighbours' finished lattices
                 HIP_TRY(hipSetDevice(hs[r]->device));
@@ -2244,8 +2264,8 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
         // columns beside it, then the edge strips once its own ghosts have landed
         {
             int kr = 1 << 30;
-            for (int r = 0; r < n && n > 1; r++) kr = std::min(kr, renew_stride(hs[r], nsteps - s));
-            if (n > 1 && kr > 0 && kr < (1 << 30)) {
+            for (int r = 0; r < n && multi; r++) kr = std::min(kr, renew_stride(hs[r], nsteps - s));
+            if (multi && kr > 0 && kr < (1 << 30)) {
                 std::vector<char> sv((size_t)n);
                 for (int r = 0; r < n; r++) {
                     HIP_TRY(hipSetDevice(hs[r]->device));
@@ -2291,7 +2311,7 @@ extern "C" int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, doub
         }
         const bool emit = (s == nsteps - 1);
         bool refresh = false;                             // as soon as ANY slab has no exact ghost column left, all of them refresh
-        for (int r = 0; r < n && n > 1; r++) refresh = refresh || hs[r]->ghost_valid <= 0;
+        for (int r = 0; r < n && multi; r++) refresh = refresh || hs[r]->ghost_valid <= 0;
         if (refresh) {
             // every slab's comm stream must see its neighbours' finished lattices ...
             for (int r = 0; r < n; r++) {

@@ -94,6 +94,35 @@ def measure_slab_cost(mask: np.ndarray, edges: List[int], rank: int, halo: int, 
         return e.step_timed(steps, tau, u0) / steps * 1e3
 
 
+def measure_slab_real(mask: np.ndarray, edges: List[int], rank: int, halo: int, dtype="float32", device: int = 0, tau: float = 0.58,
+                      u0: float = 0.06, steps: int = 0, options=None) -> dict:
+    """Slab `rank` of the split as a REAL slab handle, alone on the GPU and linked to ITSELF (wt_link_local with one handle: its ghost columns are
+    refreshed from its own owned edges — a tunnel periodic in x over this slab): the whole slab state machine runs — trimmed ghost marching, the
+    refresh mode of `options`, the exchange beside the interior — with a copy kernel as the exchange.  Returns microseconds per step and, per
+    refresh, the time of the exchange (a copy here) and of the compute that runs beside it ("interior_us": the window an exchange over the links
+    can hide in).  What measure_slab_cost approximates with a stand-alone lattice, measured on the thing itself; the exchange over xGMI is NOT in
+    it (bench.py adds its stated model: exchange_model_us)."""
+    from ._capi import Engine
+    ny, nx = mask.shape
+    with Engine(nx, ny, dtype=dtype, device=device, rank=rank, nranks=len(edges) - 1, halo=halo, edges=list(edges)) as e:
+        for k, v in (options or {}).items():
+            e.set_option(k, v)
+        Engine.link_local([e])
+        e.set_mask(mask)
+        e.init_equilibrium(u0)
+        cycle = max(halo, 1)
+        n = steps or 14 * cycle
+        Engine.step_group([e], 7 * cycle, tau, u0)          # (the plan is timed and cut again here; the clocks settle)
+        e.set_option("exchange_timing", 1)
+        ms = Engine.step_group_timed([e], n, tau, u0)[0]
+        nex = max(1.0, e.get_option("exchanges"))
+        return {"us_per_step": ms / n * 1e3, "steps": n, "exchanges": int(e.get_option("exchanges")),
+                "exchange_us": e.get_option("exchange_ms") / nex * 1e3, "interior_us": e.get_option("interior_ms") / nex * 1e3,
+                "exposed_us": e.get_option("exchange_exposed_ms") / nex * 1e3, "single_steps": int(e.get_option("single_steps")),
+                "fused_renewals": int(e.get_option("fused_renewals")), "passes": int(e.get_option("passes")), "width": e.width,
+                "sides": (1 if rank > 0 else 0) + (1 if rank < len(edges) - 2 else 0)}
+
+
 def balance_split(nx: int, nranks: int, min_width: int, measure: Callable[[List[int]], List[float]], rounds: int = 3):
     """Equal widths first, then `rounds` times: measure every slab of the split (`measure(edges)` -> cost per slab, the same list on every
     caller), cut by cost (balanced_edges).  Returns (edges of the split whose SLOWEST slab was fastest, history of (edges, costs))."""

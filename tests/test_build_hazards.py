@@ -57,3 +57,36 @@ def test_library_isa_has_no_store_data_hazard(isa_files):
         bad += b
     assert total >= 50                     # the marching kernels' store groups were seen
     assert bad == [], bad[:3]
+
+
+def test_marching_loop_instruction_budget(isa_files):
+    """The four-step fp32 kernel is bound by the vector instructions two waves per SIMD can issue, so the size of its loop is pinned here,
+    on the CPU box, where a regression costs nothing to catch: instructions EXECUTED by one trip round the chain loop on the
+    path of a plain interior column (tools/isa_loops.py follows the branches a column without body, clamp or far-field rows takes), per wave =
+    4 levels x 128 rows.  Round 4: 1096 executed / 867 vector (536 packed, 104 plain moves); round 5: 1030 / 805 (496 packed, 82 moves) with the
+    two-operation division by tau, 1066 / 841 with the three-operation one; fp64: 1211 / 1021 per 4 x 64 rows (round 4: 9 IEEE divisions per site more)."""
+    import isa_loops as L
+    f = [p for p in isa_files if "windtunnel" in os.path.basename(p)][0]
+    budget = {   # kernel symbol -> (executed, vector, packed, plain moves) upper bounds: the round-5 counts + 1 % of slack for compiler noise
+        "_ZN2wt8k_march3IfLi2ELi4ELb0ELi17EEEvNS_11MarchParamsIT_EE": (1042, 814, 496, 90),
+        "_ZN2wt8k_march3IfLi2ELi4ELb0ELi1EEEvNS_11MarchParamsIT_EE": (1078, 850, 532, 90),
+        "_ZN2wt8k_march3IdLi1ELi4ELb0ELi1EEEvNS_11MarchParamsIT_EE": (1225, 1032, 0, 56),
+    }
+    for sym, (ex_max, valu_max, pk_max, mov_max) in budget.items():
+        name, lines = L.kernel_lines(f, sym)
+        assert name == sym, sym
+        best = None
+        for tgt, a, b, c, nops in L.loops(lines):
+            if not (800 < sum(c.values()) < 4000):
+                continue
+            try:
+                cc, _ = L.follow(lines, tgt)
+            except (KeyError, IndexError):
+                continue
+            tot = sum(cc.values())
+            if 700 < tot < 1300 and cc.get("vmem", 0) == 21 and (best is None or tot < sum(best.values())):
+                best = cc                      # the chain units' loop: 9 loads + 1 halo line + 9 stores + 2 seam stores
+        assert best is not None, f"no marching loop found in {sym}"
+        valu = sum(v for k, v in best.items() if k.startswith("v_"))
+        got = (sum(best.values()), valu, best.get("v_pk", 0), best.get("v_mov", 0))
+        assert got[0] <= ex_max and got[1] <= valu_max and got[2] <= pk_max and got[3] <= mov_max, (sym, got, (ex_max, valu_max, pk_max, mov_max))
