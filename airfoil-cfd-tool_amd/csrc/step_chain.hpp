@@ -37,6 +37,11 @@ struct ChainLds {
     int flag[2][DEPTH - 1][4];           // 1 once the triple above has been written (each slot is written once per launch)
 };
 
+#ifdef WT_EXP_OLD_FLAGS      // A/B experiment: the generic volatile accesses of rounds 3-4 (flat_store / flat_load + vmcnt(0))
+typedef int lds_int_t;
+#else
+typedef __attribute__((address_space(3))) int lds_int_t;      // the hand-over flags live in LDS: say so (see chain_publish)
+#endif
 // Hand-over of a triple between two waves of a workgroup WITHOUT a barrier: the producer writes the data, then the flag (LDS operations of one
 // wave complete in order; the wait in between makes that explicit); the consumer polls the flag just before the stage that needs the data —
 // one stage or more after its partner published, so the poll almost always succeeds at once.  (A workgroup barrier per level cost 8 % of a
@@ -49,7 +54,9 @@ __device__ __forceinline__ void chain_publish(V (&slot)[3][64], int &flag, int l
     slot[1][lane] = a1;
     slot[2][lane] = a2;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    *(volatile int *)&flag = 1;
+    // (through an LDS-qualified pointer: as a generic volatile access the flag came out as flat_store_dword sc0 sc1 + s_waitcnt vmcnt(0) — every
+    //  hand-over drained the wave's prefetched column and its stores; the poll below likewise as flat_load_dword + vmcnt(0).  Round 5.)
+    *(volatile lds_int_t *)&flag = 1;
 }
 // The poll is BOUNDED: on a well-formed plan the partner publishes within a stage or two — the library checks every plan
 // it uploads (sanitize_chain_plan) — but a wave must never be able to spin for ever on a GPU other people share.  After CHAIN_POLL_LIMIT polls
@@ -60,9 +67,9 @@ template <typename V>
 __device__ __forceinline__ void chain_receive(const V (&slot)[3][64], const int &flag, int lane, V (&r)[3], unsigned int *stuck)
 {
 #ifndef WT_CHAIN_NOBARRIER   // (timing experiment: no synchronisation at all — wrong results)
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane(*(const volatile int *)&flag) == 0, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(*(const volatile lds_int_t *)&flag) == 0, 0)) {
         int polls = 0;
-        while (__builtin_amdgcn_readfirstlane(*(const volatile int *)&flag) == 0) {
+        while (__builtin_amdgcn_readfirstlane(*(const volatile lds_int_t *)&flag) == 0) {
             __builtin_amdgcn_s_sleep(1);
             if (++polls > CHAIN_POLL_LIMIT) {
                 if (lane == 0 && stuck) atomicOr(stuck, 1u);
@@ -303,6 +310,18 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     a.voff_st = (j0 < g.ny) ? (unsigned)j0 * EB : p.lat_bytes;
     a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
     a.lane = lane;
+    // One LDS pool per workgroup: the hand-over slots of a chain block, or — a workgroup is a chain block or four solo units, never both — the
+    // solo units' buffers for the own populations of general columns (own_prefetch, step_march.hpp): two per wave.
+    // (a union, so that the chain path keeps addressing its slots and flags as members of a __shared__ object: through a reinterpreted char
+    //  array the flag polls came out as FLAT loads with a vmcnt(0) wait behind them)
+    union LdsPool { ChainLds<T, S, (DEPTH >= 3 ? DEPTH : 3)> chain; char own[8 * OWN_LDS_BYTES]; };
+    __shared__ __attribute__((aligned(16))) LdsPool lds_pool;
+#ifdef WT_EXP_NO_OWN_LDS     // A/B experiment: a general column's own populations loaded at its stage 1, as in rounds 2-4
+    a.own_lds = nullptr;
+#else
+    a.own_lds = &lds_pool.own[0] + (threadIdx.x >> 6) * 2 * OWN_LDS_BYTES;
+#endif
+    a.voff_dma = (unsigned)row0 * EB + (unsigned)lane * 4u;
     // halo lines (step_march3.hpp): lanes 0..15 hold the first half of the line of (seam w, column c) — window w's words from below, levels 1, 2, 3, 0 in
     // four lanes each —, lanes 48..63 the second half of the line of (seam w+1, column c): its words from above (row 0 / row 3 of the wave: the stages
     // fetch them with row shifts, m_below_h / m_above_h)
@@ -347,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
         // per block (set by chain_blocks on the host for all four units or none), so the barriers inside are workgroup-uniform.
         if (uflags & MU_CHAIN) {
             constexpr int FDP = (DEPTH == 4 && sizeof(T) == 4) ? (FD | MARCH_FD_PACKED) : FD;
-            __shared__ ChainLds<T, S, DEPTH> chain_lds;
+            ChainLds<T, S, DEPTH> &chain_lds = lds_pool.chain;
             const bool end_shared = (uflags & MU_END_SHARED) != 0;
             if (lane < 2 * (DEPTH - 1)) chain_lds.flag[lane / (DEPTH - 1)][lane % (DEPTH - 1)][u & 3] = 0;     // my own hand-over flags ...
             __syncthreads();                                                                              // ... before anybody polls them

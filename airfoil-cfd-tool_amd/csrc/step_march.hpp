@@ -464,6 +464,8 @@ struct MarchAddr {
     T *lds_w, *lds_r;                    // this lane's LDS address for staging (write) and for the transposed read-back
     int lane;
     unsigned P4, pitch4, mp4;            // plane / column / macro-plane strides in bytes
+    char *own_lds;                       // k_march3, general (BODY) units: this wave's two LDS buffers for a column's own populations (own_prefetch); else null
+    unsigned voff_dma;                   // the lane's byte offset for a dword-per-lane LDS-DMA load of the window's first 64 dwords: row0 * sizeof(T) + 4 lane
 };
 
 // byte offset of (plane k, local column col, row shift dj) from the lattice base (one pad column in front)
@@ -878,17 +880,56 @@ __device__ __forceinline__ void march_align_in(MV<T, S> (&in)[9], int lane, T hv
     in[4] = m_above_h<12>(in[4], hv); in[7] = m_above_h<13>(in[7], hv); in[8] = m_above_h<14>(in[8], hv);
 }
 
+// ---- a general column's OWN populations, prefetched into LDS (round 5) ----
+// Step 1 of a column that touches the body needs the sites' own populations of all directions — the bounced values of half-way bounce-back
+// (html:324-334: fin[k] = f[opp(k)] of the site itself where the upstream site is solid) and the reversed populations of solid sites
+// (html:287-294).  Loaded where they are used they put a full trip to memory behind a scalar branch in the middle of an iteration: on the slab
+// over the thick part of the body these nine loads ALONE were 20 % of the pass (profiles/r05_g_own_loads.txt: 21.1 -> 16.7 us per step with the
+// loads stubbed out), and they are why a body column cost three plain ones.  There is no register to prefetch them into (242-253 VGPRs), so they
+// go to LDS instead: at the top of the iteration BEFORE the one that needs them, ahead of that iteration's own prefetch, as dword-per-lane LDS-DMA
+// loads (`buffer_load_dword ... lds`: lane i's dword lands at M0 + 4 i, so two instructions 256 bytes apart lay the window's 64 S sizeof(T) = 512
+// bytes of one population down contiguously and every lane reads its S rows back with one ds_read_b64 — layout checked by tools/kldsdma.hip).
+// Loads return in order, so the wait for the prefetched column at the end of that iteration covers them; two buffers per wave take turns (the
+// column after next is requested while this one is still to be read).  The buffers live in the LDS of the chain blocks' hand-over slots, which a
+// workgroup of solo units does not use.
+static constexpr int OWN_LDS_BYTES = 9 * 512;      // one buffer: nine populations x 512 bytes
+typedef __attribute__((address_space(3))) void *lds_void_p;
+template <typename T, int S>
+__device__ __forceinline__ void own_prefetch(const MarchAddr<T, S> &a, int col, char *buf)
+{
+    static_assert(64 * S * sizeof(T) == 512, "one population of a window's column is 512 bytes");
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const unsigned soff = lat_off(a, k, col, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rs, (lds_void_p)(buf + 512 * k), 4, a.voff_dma, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rs, (lds_void_p)(buf + 512 * k), 4, a.voff_dma, soff, 256, 0);
+    }
+}
+template <typename T, int S>
+__device__ __forceinline__ MV<T, S> own_read(const char *buf, int k, int lane)
+{
+    MV<T, S> o;
+    const u2v x = *reinterpret_cast<const u2v *>(buf + 512 * k + 8 * lane);
+    __builtin_memcpy(&o, &x, 8);
+    return o;
+}
+
 // Step 1 of column x -> G (all nine directions).  `in` holds the streamed inputs of column x (modified in place).
+// `own_buf` (optional): the LDS buffer own_prefetch filled with column x's own populations one iteration ago; null: they are loaded here.
 // `pre` (optional): the column's solid flags and bounce codes {solid4, code4}, fetched ahead by the caller (SiteBytes below)
 template <bool BODY, int FD, typename T, int S>
 __device__ __forceinline__ void march_step1(const MarchParams<T> &p, const MarchAddr<T, S> &a, int x, int j0, bool far_win, bool nonfast, bool allsolid,
-                                            const T (&feq0)[9], MV<T, S> (&in)[9], MV<T, S> (&G)[9], const uint32_t *pre = nullptr)
+                                            const T (&feq0)[9], MV<T, S> (&in)[9], MV<T, S> (&G)[9], const uint32_t *pre = nullptr, const char *own_buf = nullptr)
 {
     MV<T, S> mac[3];
     if (BODY) {
         const Geom &g = p.g;
         const int gi = x + g.gi0;
-        auto own = [&](int k) { return bload<T, S>(a.rs, a.voff, lat_off(a, k, x, 0)); };
+#ifdef WT_EXP_NO_OWN       // timing experiment (WRONG results): what do the stage-1 loads of a general column's own populations cost?
+        auto own = [&](int k) { return in[k]; };
+#else
+        auto own = [&](int k) { return own_buf ? own_read<T, S>(own_buf, k, a.lane) : bload<T, S>(a.rs, a.voff, lat_off(a, k, x, 0)); };
+#endif
         if (__builtin_expect(gi <= 0 || gi >= g.nx_g - 1 || nonfast, 0)) {
             // rare paths (scalar branches): inlet / outlet columns, body surface, body interior
             uint32_t solid4 = 0, code4 = 0;
@@ -1050,6 +1091,7 @@ __global__ __launch_bounds__(256, 2) void k_march(MarchParams<T> p)
     a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * EB;           // lanes beyond the last row re-read the window's first rows (cached) and store nothing
     a.voff_st = (j0 < g.ny) ? (unsigned)j0 * EB : p.lat_bytes;    // >= num_records of both the lattice and the macro buffer
     a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
+    a.own_lds = nullptr; a.voff_dma = 0;                          // (the LDS prefetch of a general column's own populations belongs to k_march3)
     // halo table: lanes 0..5 fetch, for step 2 of column c, {G2(c), G5(c-1), G6(c+1)} of the row below the window
     // (seam w) and {G4(c), G7(c+1), G8(c-1)} of the row above it (seam w+1); record = 8 elements per (seam, column)
     const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.halo, (unsigned)((unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * 8u * EB));

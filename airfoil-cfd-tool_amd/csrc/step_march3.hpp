@@ -522,7 +522,8 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 #define NONFAST(x) (BODY && cm_bit(nonfast_m, (x) - ia + 2))
 #define ALLSOLID(x) (BODY && cm_bit(solid_m, (x) - ia + 2))
 #define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
-#define STEP1P(x, in, G, sb) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, BODY ? (sb).v : nullptr)
+#define STEP1P(x, in, G, sb) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, BODY ? (sb).v : nullptr, \
+                                                       (BODY && own_rdy) ? a.own_lds + ((x) & 1) * OWN_LDS_BYTES : nullptr)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
     const int xend = outlet ? ib : ib + 1;       // last column whose level 1 is computed (the outlet column itself for the last unit)
     V3 s1m[3], s1c[9];           // level 1: populations 1,5,8 of column x-2; all nine of column x-1
@@ -562,9 +563,12 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     // The loop body has no branch on the pipeline fill: during the first two iterations (x - 2 < ia) level 3 is computed on
     // don't-care values and its stores are dropped by an out-of-range offset — a scalar `if` around the stage and its
     // stores makes hipcc's waitcnt pass drain vmcnt(0) at the merge points of every iteration.
+    bool own_rdy = false;        // column x's own populations are in this wave's LDS buffer (x & 1): requested one iteration ago (own_prefetch)
 #pragma unroll 1
     for (int x = ia; x <= xend; x++) {
         V3 nxt[9];
+        const bool own_pf = BODY && a.own_lds != nullptr && x + 1 <= xend && NONFAST(x + 1);
+        if (own_pf) own_prefetch<T, S>(a, x + 1, a.own_lds + ((x + 1) & 1) * OWN_LDS_BYTES);      // a general column next: its own populations, ahead of the prefetch below
         march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);              // prefetch (last one: harmless re-load)
         const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
         const int c1 = x - 1, c2 = x - 2;
@@ -598,6 +602,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         M3_STAMP(5);                                                           // issue of the stores
         seam_col = has2 ? c2 : seam_col;
         if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
+        own_rdy = own_pf;
         s2m[0] = s2c[1]; s2m[1] = s2c[5]; s2m[2] = s2c[8];
         s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
 #pragma unroll
@@ -703,9 +708,12 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     wait_for_column(in, hv0, hv1, hv2);
     wait_for_column(in, hv3);
     int seam_col = -1;
+    bool own_rdy = false;        // column x's own populations are in this wave's LDS buffer (x & 1): requested one iteration ago (own_prefetch)
 #pragma unroll 1
     for (int x = xs; x <= xend; x++) {
         V3 nxt[9];
+        const bool own_pf = BODY && a.own_lds != nullptr && x + 1 <= xend && NONFAST(x + 1);
+        if (own_pf) own_prefetch<T, S>(a, LCOL(x + 1), a.own_lds + ((x + 1) & 1) * OWN_LDS_BYTES);      // a general column next: its own populations, ahead of the prefetch below
         march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has3 = x - 3 >= ia;                                         // column x-3 is an output column
         const int c1 = x - 1, c2 = x - 2, c3 = x - 3;
@@ -714,7 +722,8 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         if (BODY) sbn = site_bytes_load<T, S>(p, x + 1, j0);
         const Seam3 sp = seam3_fetch(m);
         march_align_in(in, lane, hv0);
-        march_step1<BODY, FD, T, S>(p, a, x, j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G1, BODY ? sb0.v : nullptr);      // level 1 of column x
+        march_step1<BODY, FD, T, S>(p, a, x, j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G1, BODY ? sb0.v : nullptr,
+                                    (BODY && own_rdy) ? a.own_lds + (x & 1) * OWN_LDS_BYTES : nullptr);                     // level 1 of column x
         march_stage<BODY, false, FD, 0>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);     // level 2 of x-1
         march_stage<BODY, false, FD, 4>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, G3, mac, BODY ? sb2.v : nullptr);     // level 3 of x-2
         V3 out[9];
@@ -727,6 +736,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         seam3_flush(m, seam_col, sp);
         seam_col = has3 ? c3 : seam_col;
         if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
+        own_rdy = own_pf;
         s3m[0] = s3c[1]; s3m[1] = s3c[5]; s3m[2] = s3c[8];
         s2m[0] = s2c[1]; s2m[1] = s2c[5]; s2m[2] = s2c[8];
         s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];

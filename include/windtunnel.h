@@ -143,10 +143,17 @@ WT_API const char *wt_version(void);
  *       remaining depth, cut from the kept plan's column costs the first time it is needed.  Between two refreshes a slab with halo 17 marches
  *       12, 8, 4 and 0 ghost columns per side instead of 14 four times.  "trimmed_passes" counts the passes that ran on a trimmed list.
  *   "refresh" (default 0, slab handles): how the ghost columns are renewed.  0: by a SINGLE step (k_step) whose interior columns run beside the
- *       exchange, the two edge strips after it — the exchange hides, the step runs at the un-fused rate and the pass after it builds its halo
- *       tables by the gather path.  1: by an exchange at a PASS BOUNDARY — nothing runs beside it, and every step of the cycle is a fused one
- *       ("single_steps" stays 0, "boundary_exchanges" counts them; wt_plan_steps reports such an exchange as -2).  Which is faster depends on
- *       what an exchange costs on the links (profiles/r04_h_refresh_modes.txt); all slabs of a tunnel must choose alike (checked).
+ *       exchange, the two edge strips (the ghost columns + one owned column: a few microseconds) after it — the step runs at the un-fused rate
+ *       and the pass after it builds its halo lines by the gather path.  1: by an exchange at a PASS BOUNDARY — nothing runs beside it, and every
+ *       step of the cycle is a fused one ("single_steps" stays 0, "boundary_exchanges" counts them; wt_plan_steps reports such an exchange as -2).
+ *       2 (round 5): INSIDE a fused pass of k steps — the exchange runs beside the marching of the interior columns [gl + k, gl + width - k), the
+ *       two edge strips (the k owned columns next to each edge and the ghost columns that stay exact) are marched once the ghosts have landed;
+ *       no single step, no exchange outside a pass ("fused_renewals" counts them; wt_plan_steps reports 100 + k), and the window an exchange
+ *       can hide in is a whole pass instead of one k_step.  Measured on the real 8-way split of the 4096^2 tunnel (one slab at a time, linked
+ *       to itself: profiles/r05_e_slab_costs_cfg2.txt): 0 = 21.5 us per step with a copy kernel as the exchange, 22.2 with the modelled
+ *       exchange over one xGMI link (67.7 us per refresh, 30 of them exposed); 2 = 23.2 either way (nothing exposed, but the strips of a
+ *       four-step pass cost more behind the exchange than the one-column strips of a single step): 0 stays the default.  All slabs of a
+ *       tunnel must choose alike (checked).
  *   "agree_check" (default 1, slab handles): every slab of a tunnel must take the SAME sequence of fused passes, single steps and ghost
  *       refreshes — over RCCL each rank decides alone and the exchange is collective, so a rank that decides differently is a hang.  The
  *       library therefore compares, across the slabs, everything that decides that sequence (lattice, split, halo, dtype, the options above,
@@ -200,7 +207,10 @@ WT_API int wt_comm_selftest(int device, int ny);
 /* In-process transport: all slabs of one tunnel live in the calling process
  * (any mix of devices); ghost columns move by peer copies.  `hs` are the
  * nranks slab handles ordered by rank.  Stepping then goes through
- * wt_step_group, which advances every slab in lock-step. */
+ * wt_step_group, which advances every slab in lock-step.
+ * n = 1 with a slab handle links that slab to ITSELF: its ghost columns are refreshed from its own owned edge columns (a tunnel periodic in x
+ * over this slab; needs width >= 2 halo).  The timing stand-in for one slab of a split — trimmed ghost marching, the refresh mode, the exchange
+ * beside the interior all run, on one handle alone on the GPU (distributed.measure_slab_real, tools/r5_slab_costs.py). */
 WT_API int wt_link_local(wt_handle **hs, int n);
 WT_API int wt_step_group(wt_handle **hs, int n, int nsteps, double tau, double u0);
 /* As wt_step_group, every slab's share bracketed by HIP events on that slab's compute stream; blocks, and returns the
