@@ -37,11 +37,7 @@ struct ChainLds {
     int flag[2][DEPTH - 1][4];           // 1 once the triple above has been written (each slot is written once per launch)
 };
 
-#ifdef WT_EXP_OLD_FLAGS      // A/B experiment: the generic volatile accesses of rounds 3-4 (flat_store / flat_load + vmcnt(0))
-typedef int lds_int_t;
-#else
 typedef __attribute__((address_space(3))) int lds_int_t;      // the hand-over flags live in LDS: say so (see chain_publish)
-#endif
 // Hand-over of a triple between two waves of a workgroup WITHOUT a barrier: the producer writes the data, then the flag (LDS operations of one
 // wave complete in order; the wait in between makes that explicit); the consumer polls the flag just before the stage that needs the data —
 // one stage or more after its partner published, so the poll almost always succeeds at once.  (A workgroup barrier per level cost 8 % of a
@@ -316,11 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     //  array the flag polls came out as FLAT loads with a vmcnt(0) wait behind them)
     union LdsPool { ChainLds<T, S, (DEPTH >= 3 ? DEPTH : 3)> chain; char own[8 * OWN_LDS_BYTES]; };
     __shared__ __attribute__((aligned(16))) LdsPool lds_pool;
-#ifdef WT_EXP_NO_OWN_LDS     // A/B experiment: a general column's own populations loaded at its stage 1, as in rounds 2-4
-    a.own_lds = nullptr;
-#else
     a.own_lds = &lds_pool.own[0] + (threadIdx.x >> 6) * 2 * OWN_LDS_BYTES;
-#endif
     a.voff_dma = (unsigned)row0 * EB + (unsigned)lane * 4u;
     // halo lines (step_march3.hpp): lanes 0..15 hold the first half of the line of (seam w, column c) — window w's words from below, levels 1, 2, 3, 0 in
     // four lanes each —, lanes 48..63 the second half of the line of (seam w+1, column c): its words from above (row 0 / row 3 of the wave: the stages

@@ -889,8 +889,8 @@ __device__ __forceinline__ void march_align_in(MV<T, S> (&in)[9], int lane, T hv
 // go to LDS instead: at the top of the iteration BEFORE the one that needs them, ahead of that iteration's own prefetch, as dword-per-lane LDS-DMA
 // loads (`buffer_load_dword ... lds`: lane i's dword lands at M0 + 4 i, so two instructions 256 bytes apart lay the window's 64 S sizeof(T) = 512
 // bytes of one population down contiguously and every lane reads its S rows back with one ds_read_b64 — layout checked by tools/kldsdma.hip).
-// Loads return in order, so the wait for the prefetched column at the end of that iteration covers them; two buffers per wave take turns (the
-// column after next is requested while this one is still to be read).  The buffers live in the LDS of the chain blocks' hand-over slots, which a
+// Loads return in order, so the wait for the prefetched column at the end of that iteration covers them (and hipcc's wait-count pass, which knows
+// that these loads write LDS, puts an s_waitcnt vmcnt(n) in front of the reads where it cannot see that); two buffers per wave take turns.  The buffers live in the LDS of the chain blocks' hand-over slots, which a
 // workgroup of solo units does not use.
 static constexpr int OWN_LDS_BYTES = 9 * 512;      // one buffer: nine populations x 512 bytes
 typedef __attribute__((address_space(3))) void *lds_void_p;
@@ -915,9 +915,10 @@ __device__ __forceinline__ MV<T, S> own_read(const char *buf, int k, int lane)
 }
 
 // Step 1 of column x -> G (all nine directions).  `in` holds the streamed inputs of column x (modified in place).
-// `own_buf` (optional): the LDS buffer own_prefetch filled with column x's own populations one iteration ago; null: they are loaded here.
+// OWN_LDS: the column's own populations (general columns only) are in the LDS buffer `own_buf`, requested by own_prefetch — one iteration ago in the
+// units' loops, just now for a unit's first columns; false (the two-step kernel): they are loaded here.
 // `pre` (optional): the column's solid flags and bounce codes {solid4, code4}, fetched ahead by the caller (SiteBytes below)
-template <bool BODY, int FD, typename T, int S>
+template <bool BODY, int FD, typename T, int S, bool OWN_LDS = false>
 __device__ __forceinline__ void march_step1(const MarchParams<T> &p, const MarchAddr<T, S> &a, int x, int j0, bool far_win, bool nonfast, bool allsolid,
                                             const T (&feq0)[9], MV<T, S> (&in)[9], MV<T, S> (&G)[9], const uint32_t *pre = nullptr, const char *own_buf = nullptr)
 {
@@ -928,7 +929,10 @@ __device__ __forceinline__ void march_step1(const MarchParams<T> &p, const March
 #ifdef WT_EXP_NO_OWN       // timing experiment (WRONG results): what do the stage-1 loads of a general column's own populations cost?
         auto own = [&](int k) { return in[k]; };
 #else
-        auto own = [&](int k) { return own_buf ? own_read<T, S>(own_buf, k, a.lane) : bload<T, S>(a.rs, a.voff, lat_off(a, k, x, 0)); };
+        auto own = [&](int k) {
+            if constexpr (OWN_LDS) return own_read<T, S>(own_buf, k, a.lane);
+            else return bload<T, S>(a.rs, a.voff, lat_off(a, k, x, 0));
+        };
 #endif
         if (__builtin_expect(gi <= 0 || gi >= g.nx_g - 1 || nonfast, 0)) {
             // rare paths (scalar branches): inlet / outlet columns, body surface, body interior

@@ -521,9 +521,12 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     const MarchAddr<T, S> &a = m.a;
 #define NONFAST(x) (BODY && cm_bit(nonfast_m, (x) - ia + 2))
 #define ALLSOLID(x) (BODY && cm_bit(solid_m, (x) - ia + 2))
-#define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
-#define STEP1P(x, in, G, sb) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, BODY ? (sb).v : nullptr, \
-                                                       (BODY && own_rdy) ? a.own_lds + ((x) & 1) * OWN_LDS_BYTES : nullptr)
+    // a general column's own populations come out of this wave's LDS buffer (x & 1) (step_march.hpp own_prefetch): requested one iteration ahead in
+    // the loop, on the spot (OWN_NOW) for the unit's first columns
+#define OWN_BUF(x) (a.own_lds + ((x) & 1) * OWN_LDS_BYTES)
+#define OWN_NOW(x) do { if (BODY && NONFAST(x)) own_prefetch<T, S>(a, (x), OWN_BUF(x)); } while (0)
+#define STEP1(x, in, G) march_step1<BODY, FD, T, S, BODY>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, nullptr, OWN_BUF(x))
+#define STEP1P(x, in, G, sb) march_step1<BODY, FD, T, S, BODY>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, BODY ? (sb).v : nullptr, OWN_BUF(x))
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
     const int xend = outlet ? ib : ib + 1;       // last column whose level 1 is computed (the outlet column itself for the last unit)
     V3 s1m[3], s1c[9];           // level 1: populations 1,5,8 of column x-2; all nine of column x-1
@@ -541,16 +544,19 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     T hv1 = halo_load<T>(rh, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);          // column x-1
     T hv0 = halo_load<T>(rh, hoff, (unsigned)ia * HREC);                                 // column x
     if (!BODY || ia - 2 + g.gi0 >= 0) {
+        OWN_NOW(ia - 2);
         march_load_aligned(a, ia - 2, in);
         march_align_in(in, lane, hv2);
         STEP1(ia - 2, in, s1c);
     }
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     if (!BODY || ia - 1 + g.gi0 >= 0) {
+        OWN_NOW(ia - 1);
         march_load_aligned(a, ia - 1, in);
         march_align_in(in, lane, hv1);
         STEP1(ia - 1, in, s1c);
     }
+    OWN_NOW(ia);
     march_load_aligned(a, ia, in);
     // site bytes of columns x, x-1, x-2 (general loop only; see SiteBytes)
     SiteBytes sb0{{0, 0}}, sb1{{0, 0}}, sb2{{0, 0}};
@@ -563,12 +569,12 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     // The loop body has no branch on the pipeline fill: during the first two iterations (x - 2 < ia) level 3 is computed on
     // don't-care values and its stores are dropped by an out-of-range offset — a scalar `if` around the stage and its
     // stores makes hipcc's waitcnt pass drain vmcnt(0) at the merge points of every iteration.
-    bool own_rdy = false;        // column x's own populations are in this wave's LDS buffer (x & 1): requested one iteration ago (own_prefetch)
 #pragma unroll 1
     for (int x = ia; x <= xend; x++) {
         V3 nxt[9];
-        const bool own_pf = BODY && a.own_lds != nullptr && x + 1 <= xend && NONFAST(x + 1);
-        if (own_pf) own_prefetch<T, S>(a, x + 1, a.own_lds + ((x + 1) & 1) * OWN_LDS_BYTES);      // a general column next: its own populations, ahead of the prefetch below
+        // a general column next: its own populations on their way into LDS (own_prefetch), AHEAD of this iteration's prefetch — loads return in
+        // order, so the wait for the prefetched column at the end of the iteration covers them (behind stage 1 instead: the plain slabs ran 4 % slower)
+        if (BODY && x + 1 <= xend && NONFAST(x + 1)) own_prefetch<T, S>(a, x + 1, OWN_BUF(x + 1));
         march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);              // prefetch (last one: harmless re-load)
         const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
         const int c1 = x - 1, c2 = x - 2;
@@ -602,7 +608,6 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         M3_STAMP(5);                                                           // issue of the stores
         seam_col = has2 ? c2 : seam_col;
         if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
-        own_rdy = own_pf;
         s2m[0] = s2c[1]; s2m[1] = s2c[5]; s2m[2] = s2c[8];
         s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
 #pragma unroll
@@ -651,6 +656,8 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 #undef ALLSOLID
 #undef STEP1
 #undef STEP1P
+#undef OWN_BUF
+#undef OWN_NOW
 }
 
 // FOUR steps per pass: one more level (s3m / s3c) and one more stage than march_unit3; the pipeline starts one column earlier
@@ -668,7 +675,9 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     // (the level-4 stage of the first iteration works on column ia-4, outside the masks: no class -> plain / inlet branch, no mask access)
 #define NONFAST(x) (BODY && (x) >= ia - 3 && cm_bit(nonfast_m, (x) - ia + 3))
 #define ALLSOLID(x) (BODY && (x) >= ia - 3 && cm_bit(solid_m, (x) - ia + 3))
-#define STEP1(x, in, G) march_step1<BODY, FD, T, S>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G)
+#define OWN_BUF(x) (a.own_lds + ((x) & 1) * OWN_LDS_BYTES)
+#define OWN_NOW(x) do { if (BODY && NONFAST(x)) own_prefetch<T, S>(a, (x), OWN_BUF(x)); } while (0)      // (see march_unit3)
+#define STEP1(x, in, G) march_step1<BODY, FD, T, S, BODY>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, nullptr, OWN_BUF(x))
 #define HCOL(c) ((unsigned)((c) > 0 ? (c) : 0) * HREC)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
     const int xend = outlet ? ib : ib + 2;       // last column whose level 1 is computed
@@ -688,16 +697,19 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     T hv3 = halo_load<T>(rh, hoff, HCOL(xs - 3)), hv2 = halo_load<T>(rh, hoff, HCOL(xs - 2)), hv1 = halo_load<T>(rh, hoff, HCOL(xs - 1)),
       hv0 = halo_load<T>(rh, hoff, HCOL(xs));
     if (!BODY || ia - 3 + g.gi0 >= 0) {
+        OWN_NOW(ia - 3);
         march_load_aligned(a, ia - 3, in);
         march_align_in(in, lane, hv2);          // ia - 3 = xs - 2
         STEP1(ia - 3, in, s1c);
     }
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     if (!BODY || ia - 2 + g.gi0 >= 0) {
+        OWN_NOW(ia - 2);
         march_load_aligned(a, ia - 2, in);
         march_align_in(in, lane, hv1);          // ia - 2 = xs - 1
         STEP1(ia - 2, in, s1c);
     }
+    OWN_NOW(xs);                                // (a column left of the inlet carries no class)
     march_load_aligned(a, LCOL(xs), in);
     // site bytes of columns x, x-1, x-2, x-3 (general loop only; see SiteBytes)
     SiteBytes sb0{{0, 0}}, sb1{{0, 0}}, sb2{{0, 0}}, sb3{{0, 0}};
@@ -708,12 +720,10 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     wait_for_column(in, hv0, hv1, hv2);
     wait_for_column(in, hv3);
     int seam_col = -1;
-    bool own_rdy = false;        // column x's own populations are in this wave's LDS buffer (x & 1): requested one iteration ago (own_prefetch)
 #pragma unroll 1
     for (int x = xs; x <= xend; x++) {
         V3 nxt[9];
-        const bool own_pf = BODY && a.own_lds != nullptr && x + 1 <= xend && NONFAST(x + 1);
-        if (own_pf) own_prefetch<T, S>(a, LCOL(x + 1), a.own_lds + ((x + 1) & 1) * OWN_LDS_BYTES);      // a general column next: its own populations, ahead of the prefetch below
+        if (BODY && x + 1 <= xend && NONFAST(x + 1)) own_prefetch<T, S>(a, x + 1, OWN_BUF(x + 1));      // (see march_unit3)
         march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has3 = x - 3 >= ia;                                         // column x-3 is an output column
         const int c1 = x - 1, c2 = x - 2, c3 = x - 3;
@@ -722,8 +732,8 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         if (BODY) sbn = site_bytes_load<T, S>(p, x + 1, j0);
         const Seam3 sp = seam3_fetch(m);
         march_align_in(in, lane, hv0);
-        march_step1<BODY, FD, T, S>(p, a, x, j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G1, BODY ? sb0.v : nullptr,
-                                    (BODY && own_rdy) ? a.own_lds + (x & 1) * OWN_LDS_BYTES : nullptr);                     // level 1 of column x
+        march_step1<BODY, FD, T, S, BODY>(p, a, x, j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G1, BODY ? sb0.v : nullptr, OWN_BUF(x));      // level 1 of column x
+
         march_stage<BODY, false, FD, 0>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);     // level 2 of x-1
         march_stage<BODY, false, FD, 4>(p, c2, j0, lane, far_win, NONFAST(c2), ALLSOLID(c2), feq0, s2m, s2c, G2, hv2, G3, mac, BODY ? sb2.v : nullptr);     // level 3 of x-2
         V3 out[9];
@@ -736,7 +746,6 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         seam3_flush(m, seam_col, sp);
         seam_col = has3 ? c3 : seam_col;
         if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
-        own_rdy = own_pf;
         s3m[0] = s3c[1]; s3m[1] = s3c[5]; s3m[2] = s3c[8];
         s2m[0] = s2c[1]; s2m[1] = s2c[5]; s2m[2] = s2c[8];
         s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
@@ -793,6 +802,8 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
 #undef NONFAST
 #undef ALLSOLID
 #undef STEP1
+#undef OWN_BUF
+#undef OWN_NOW
 #undef HCOL
 #undef LCOL
 }
