@@ -93,3 +93,21 @@ def test_default_halo_is_clamped_to_the_narrowest_slab():
     assert default_halo(slab_bounds(100, 8)) == 12
     assert default_halo(slab_bounds(4096, 3, [0, 10, 2000, 4096])) == 10
     assert default_halo(slab_bounds(128, 8), 32) == 32                  # an explicit value is the caller's (and fails loudly in wt_create_slab)
+
+
+def test_exchange_cost_model_of_the_rank_report():
+    """bench.py's stated exchange model: 9 populations x halo columns x pitch x element size per side and refresh, one xGMI link per
+    side at 76.8 GB/s per direction + 12 us fixed; an edge slab exchanges on one side, an inner slab on two (in parallel: the model is per side)."""
+    import bench
+    m = bench.exchange_model(29, 4096, 4, 2)
+    assert m["exchange_bytes_each"] == 9 * 29 * 4096 * 4 == 4276224 and m["exchange_sides"] == 2
+    assert abs(m["exchange_model_us"] - (12.0 + 4276224 / 76.8e3)) < 1e-9 and 67.0 < m["exchange_model_us"] < 68.5
+    assert bench.exchange_model(29, 1000, 8, 1)["exchange_bytes_each"] == 9 * 29 * 1024 * 8            # the pitch: NY rounded to 256 rows
+    assert bench.exchange_model(16, 4096, 4, 0)["exchange_model_us"] == 0.0                               # a one-slab tunnel exchanges nothing
+
+
+def test_bound_is_mixed_when_the_two_fractions_are_close():
+    """valu_busy_frac saturates near 0.9 and is normalised by it; two fractions within 0.1 name no single bound."""
+    import bench
+    src = open(bench.__file__).read()
+    assert '"mixed" if abs(valu_cmp - hbm_cmp) < 0.1' in src and "valu_frac / 0.9" in src
