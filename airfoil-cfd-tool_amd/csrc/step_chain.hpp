@@ -95,19 +95,20 @@ __device__ __forceinline__ void chain_stage(const MarchParams<T> &p, int j0, int
 {
     typedef MV<T, S> V3;
     typedef ChainPops<DIR> P;
+    constexpr bool OVL = (FD & MARCH_FD_OVL) != 0;
     // the word of population k's row outside the window: slot 0 = 2 / 4 (own column), 1 = 5 / 7, 2 = 6 / 8 (step_march3.hpp, halo lines)
     constexpr int SB1 = P::B1 == 5 ? 1 : 2, SA1 = P::A1 == 5 ? 1 : 2;          // from below: populations 5, 6
     constexpr int SB2 = P::B2 == 7 ? 1 : 2, SA2 = P::A2 == 7 ? 1 : 2;          // from above: populations 7, 8
     V3 fin[9];
     fin[0] = Gc[0];
-    fin[2] = m_below_h<LB>(Gc[2], hv);
-    fin[4] = m_above_h<LB>(Gc[4], hv);
+    fin[2] = m_below_x<LB, OVL>(Gc[2], hv);
+    fin[4] = m_above_x<LB, OVL>(Gc[4], hv);
     fin[P::B0] = mb[0];
-    fin[P::B1] = m_below_h<LB + SB1>(mb[1], hv);
-    fin[P::B2] = m_above_h<LB + SB2>(mb[2], hv);
+    fin[P::B1] = m_below_x<LB + SB1, OVL>(mb[1], hv);
+    fin[P::B2] = m_above_x<LB + SB2, OVL>(mb[2], hv);
     fin[P::A0] = ma[0];
-    fin[P::A1] = m_below_h<LB + SA1>(ma[1], hv);
-    fin[P::A2] = m_above_h<LB + SA2>(ma[2], hv);
+    fin[P::A1] = m_below_x<LB + SA1, OVL>(ma[1], hv);
+    fin[P::A2] = m_above_x<LB + SA2, OVL>(ma[2], hv);
     march_collide<T, S, FD, WANT_MACRO>(fin, p.fdv, p.tau, out, mac);
     if (far_win) march_far_rows<T, S, WANT_MACRO>(j0, p.g.ny, p.U0, feq0, out, mac);
 }
@@ -118,6 +119,7 @@ struct ChainUnit {
     typedef ChainPops<DIR> P;
     static constexpr unsigned HREC = M3_HL * sizeof(T);
     static constexpr int FULL = (1 << DEPTH) - 1;
+    static constexpr bool OVLF = (FD & MARCH_FD_OVL) != 0;
 
     const MarchParams<T> &p;
     March3Addr<T, S> &m;
@@ -170,12 +172,12 @@ struct ChainUnit {
         constexpr bool S1 = (MASK & 1) != 0, LAST = (MASK >> (DEPTH - 1)) != 0;
         V3 nxt[9];
         if (S1) march_load_aligned(a, clampx(x + DIR), nxt);
-        const T hvn = halo_load<T>(rh, hoff, hcol(x + DIR));    // column x + DIR's halo line: the next iteration's stage 1, then handed on
+        const T hvn = halo_load_x<OVLF, T>(rh, hoff, hcol(x + DIR));    // column x + DIR's halo line: the next iteration's stage 1, then handed on
         Seam3 sp;
-        if (LAST) sp = seam3_fetch(m);
+        if (LAST) sp = seam3_fetch<OVLF>(m);
         V3 G[DEPTH + 1][9], mac[3];          // G[k] = level k computed in this iteration (G[DEPTH] = what is stored)
         if (S1) {
-            march_align_in(in, lane, hv[0]);
+            march_align_in<OVLF>(in, lane, hv[0]);
             march_step1<false, FD, T, S>(p, a, x, j0, far_win, false, false, feq0, in, G[1]);
             if (PS == 1) chain_publish(lds.x[0][0][pos], lds.flag[0][0][pos], lane, G[1][P::A0], G[1][P::A1], G[1][P::A2]);
             if (PE == 1) chain_publish(lds.x[1][0][pos], lds.flag[1][0][pos], lane, G[1][P::B0], G[1][P::B1], G[1][P::B2]);
@@ -188,8 +190,8 @@ struct ChainUnit {
             pin_after(G[DEPTH]);
             if (S1) wait_for_column(nxt, hvn);
             const int c = x - (DEPTH - 1) * DIR;
-            march3_store<EMIT>(m, a.voff_st, c, G[DEPTH], mac);
-            seam3_flush(m, seam_col, sp);
+            march3_store<EMIT, OVLF>(m, a.voff_st, c, G[DEPTH], mac);
+            seam3_flush<OVLF>(m, seam_col, sp);
             seam_col = c;
         }
 #pragma unroll
@@ -227,7 +229,7 @@ struct ChainUnit {
         }
         march_load_aligned(a, xf, in);
 #pragma unroll
-        for (int k = 0; k < DEPTH; k++) hv[k] = halo_load<T>(rh, hoff, hcol(xf - k * DIR));
+        for (int k = 0; k < DEPTH; k++) hv[k] = halo_load_x<OVLF, T>(rh, hoff, hcol(xf - k * DIR));
         // ---- start seam: iteration q brings level q + 1 of the first column into being and publishes its backward-moving populations; the
         //      partner's forward-moving ones are taken one iteration later, just before the stage that needs them
         iter<1, 0, 1, 0, 0>(xf);
@@ -255,7 +257,7 @@ struct ChainUnit {
                 iter<(FULL & ~7), 0, 0, 3, 0>(xl + 3 * DIR);
             }
         }
-        seam3_flush(m, seam_col, seam3_fetch(m));
+        seam3_flush<OVLF>(m, seam_col, seam3_fetch<OVLF>(m));
     }
 };
 
@@ -264,16 +266,21 @@ struct ChainUnit {
 // ------------------------------------------------------------------------------------------------
 // How long does every unit of a pass take?  Tuning passes (tune_fuse_plan in windtunnel.hip; tools/unit_clocks.py) hand a buffer over:
 // [unit] = {start, end} in s_memtime ticks.  Ordinary passes carry a null pointer and pay one scalar read of the clock.
+#ifdef WT_CLOCK_REALTIME      // diagnostic build (tools/unit_timeline.py): the constant 100 MHz counter all XCDs share, for a timeline of one launch
+#define WT_UNIT_TICKS() __builtin_amdgcn_s_memrealtime()
+#else
+#define WT_UNIT_TICKS() __builtin_amdgcn_s_memtime()
+#endif
 struct UnitClock {
     unsigned long long *clk;
     int u, lane;
     unsigned long long t0;
-    __device__ __forceinline__ UnitClock(unsigned long long *clk_, int u_, int lane_) : clk(clk_), u(u_), lane(lane_), t0(clk_ ? __builtin_amdgcn_s_memtime() : 0ULL) {}
+    __device__ __forceinline__ UnitClock(unsigned long long *clk_, int u_, int lane_) : clk(clk_), u(u_), lane(lane_), t0(clk_ ? WT_UNIT_TICKS() : 0ULL) {}
     __device__ __forceinline__ ~UnitClock()
     {
         if (clk) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            const unsigned long long t1 = WT_UNIT_TICKS();
             if (lane == 0) { clk[2 * u] = t0; clk[2 * u + 1] = t1; }
         }
     }
@@ -294,16 +301,27 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     const int w = __builtin_amdgcn_readfirstlane(un.w), uflags = __builtin_amdgcn_readfirstlane(un.flags);
     if (ib <= ia) return;
     UnitClock unit_clock(p.clk, u, lane);
-    const int row0 = w * M3_WIN;
+    // Window w = rows row0 .. row0 + WIN - 1.  Windows that TILE the column (row0 = w WIN) take the rows beyond their seams, level by level, out of the
+    // halo lines the halo kernel builds before every pass.  OVERLAPPING windows (the instantiations with MARCH_FD_OVL in FD: row0 = w (WIN - 8) - 4)
+    // carry a margin of four rows on either side instead: a margin row loses one row of validity per level — whatever arrives from beyond the window
+    // is don't-care —, so after up to four levels the WIN - 8 rows in between are exact, and only those are stored.  No halo lines, no halo kernel, no
+    // seam buffer to keep valid, six data-parallel moves per stage instead of twelve; 128 / 120 of the arithmetic (fp32).  The host launches these
+    // instantiations for a plan whose tables were built for such windows (windtunnel.hip build_fuse_plan: option window_overlap, p.win_stride).
+    constexpr bool OVL = (FD & MARCH_FD_OVL) != 0;
+    constexpr int STRIDE = OVL ? M3_WIN - 8 : M3_WIN, ROW_OFF = OVL ? -4 : 0;
+    const int row0 = w * STRIDE + ROW_OFF;
     const int j0 = row0 + lane * S;
-    const bool far_win = (w == 0) || (row0 + M3_WIN >= g.ny);
+    const bool far_win = OVL ? (row0 <= 0 || row0 + M3_WIN >= g.ny) : ((w == 0) || (row0 + M3_WIN >= g.ny));
+    // rows a lane owns (stores): tiling windows all of theirs that exist; overlapping windows those outside the two four-row margins
+    const bool owns = OVL ? (j0 >= 0 && j0 < g.ny && lane >= 4 / S && lane < 64 - 4 / S) : (j0 < g.ny);
     March3Addr<T, S> m;
     MarchAddr<T, S> &a = m.a;
     a.rs = march_rsrc(p.fs, p.lat_bytes);
     a.rd = march_rsrc(p.fd, p.lat_bytes);
     a.rm = march_rsrc(p.macro, (unsigned)(3u * (unsigned)g.nxl * (unsigned)g.pitch * EB));
-    a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * EB;
-    a.voff_st = (j0 < g.ny) ? (unsigned)j0 * EB : p.lat_bytes;
+    if constexpr (OVL) a.voff = (unsigned)((j0 >= 0 && j0 < g.ny) ? j0 : (row0 > 0 ? row0 : 0)) * EB;      // (rows that do not exist: any that do — don't-care values)
+    else a.voff = (unsigned)((j0 < g.ny) ? j0 : row0) * EB;
+    a.voff_st = owns ? (unsigned)j0 * EB : p.lat_bytes;
     a.P4 = (unsigned)g.plane * EB; a.pitch4 = (unsigned)g.pitch * EB; a.mp4 = (unsigned)g.nxl * (unsigned)g.pitch * EB;
     a.lane = lane;
     // One LDS pool per workgroup: the hand-over slots of a chain block, or — a workgroup is a chain block or four solo units, never both — the
@@ -313,14 +331,17 @@ __global__ __launch_bounds__(256, 2) void k_march3(MarchParams<T> p)
     union LdsPool { ChainLds<T, S, (DEPTH >= 3 ? DEPTH : 3)> chain; char own[8 * OWN_LDS_BYTES]; };
     __shared__ __attribute__((aligned(16))) LdsPool lds_pool;
     a.own_lds = &lds_pool.own[0] + (threadIdx.x >> 6) * 2 * OWN_LDS_BYTES;
-    a.voff_dma = (unsigned)row0 * EB + (unsigned)lane * 4u;
+    // (overlapping windows: window 0 starts four rows below row 0, so the offset is kept 256 bytes high and own_prefetch takes them off the scalar
+    //  offset again — the margin's dwords then come out of the end of the column before, which exists: don't-care values)
+    a.voff_dma = (unsigned)(row0 * (int)EB + lane * 4 + (OVL ? 256 : 0));
     // halo lines (step_march3.hpp): lanes 0..15 hold the first half of the line of (seam w, column c) — window w's words from below, levels 1, 2, 3, 0 in
     // four lanes each —, lanes 48..63 the second half of the line of (seam w+1, column c): its words from above (row 0 / row 3 of the wave: the stages
     // fetch them with row shifts, m_below_h / m_above_h)
     const unsigned hbytes = (unsigned)(p.nwin_total + 1) * (unsigned)(g.nxl + 2) * (unsigned)M3_HL * EB;
     const __amdgpu_buffer_rsrc_t rh = march_rsrc(p.hlines, hbytes);
     const unsigned hoff = (unsigned)(lane >= 48 ? ((w + 1) * (g.nxl + 2) + 1) * M3_HL + lane - 32 : (w * (g.nxl + 2) + 1) * M3_HL + (lane < 16 ? lane : 0)) * EB;
-    {
+    if constexpr (OVL) { m.lds_w = nullptr; m.lds_r = nullptr; m.voff_lo = m.voff_hi = 0; m.rs3 = a.rs; }
+    else {
         // per wave, in elements: below[40] (slot k = the window's last four rows of direction k, staged by the last 4/S lanes; slot
         // 9 stays zero), above[40] (rows 0..3, the first 4/S lanes), then a scratch area for the other lanes' writes
         constexpr int EDGE = 4 / S;                       // lanes that hold four rows

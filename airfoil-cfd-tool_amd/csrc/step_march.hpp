@@ -69,6 +69,8 @@ static inline int march_nwin(int ny, int win) { return (ny + win - 1) / win; }
 // collision for either element type: fp32 with the division selected by FD (d2q9.hpp), fp64 always IEEE
 static constexpr int MARCH_FD_CONTRACTED = 8;    // bit 3 of FD: the opt-in contracted collision (d2q9.hpp collide_contracted; fp32 only)
 static constexpr int MARCH_FD_TWOOP = 16;        // bit 4 of FD: the two-operation division by tau (d2q9.hpp; fp32, proved per tau like the three-operation one)
+static constexpr int MARCH_FD_OVL = 32;          // bit 5 of FD (k_march3): OVERLAPPING windows — no halo lines, no seam buffer (step_chain.hpp k_march3); not an arithmetic choice,
+                                                 // carried in FD because every function of the marching loop already takes it
 template <typename T, int FD>
 __device__ __forceinline__ void collide_t(const T (&fin)[9], const FastDiv &fdv, T tau, T (&fo)[9], T &rho, T &ux, T &uy)
 {
@@ -82,7 +84,8 @@ __device__ __forceinline__ void collide_t(const T (&fin)[9], const FastDiv &fdv,
 // once per mask upload
 // ------------------------------------------------------------------------------------------------
 // wcls[w * ld + (x + 1)], x = -1 .. nxl (the two extra columns are FAST), ld = nxl + 2
-__global__ __launch_bounds__(256) void k_classify_windows(const uint8_t *__restrict__ mask, uint8_t *__restrict__ wcls, Geom g, int nwin, int win)
+// (window w = rows w * stride + off .. + win - 1: stride = win, off = 0 for windows that tile the column; overlapping windows: k_march3)
+__global__ __launch_bounds__(256) void k_classify_windows(const uint8_t *__restrict__ mask, uint8_t *__restrict__ wcls, Geom g, int nwin, int win, int stride, int off)
 {
     const int lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -91,14 +94,14 @@ __global__ __launch_bounds__(256) void k_classify_windows(const uint8_t *__restr
     const int w = (int)(tile / ld), x = (int)(tile % ld) - 1;
     uint8_t cls = WC_FAST;
     if (x >= 0 && x < g.nxl) {
-        const int j0 = w * win;
+        const int j0 = w * stride + off;
         const uint8_t *m = mask + g.pitch;
         int nb = 0, own_all = 1;
         for (int jj = j0 - 1 + lane; jj <= j0 + win; jj += 64) {
             if (jj < 0 || jj >= g.ny) continue;
             const int a = m[(long)(x - 1) * g.pitch + jj], b = m[(long)x * g.pitch + jj], c = m[(long)(x + 1) * g.pitch + jj];
             nb |= a | b | c;
-            if (jj >= j0 && jj < j0 + win) own_all &= (b != 0);
+            if (jj >= j0 && jj < j0 + win) own_all &= (b != 0);      // (rows outside the lattice — a window that overlaps its end — do not count)
         }
         const bool any_nb = __ballot(nb != 0) != 0ULL;
         const bool all_own = __ballot(own_all == 0) == 0ULL;
@@ -292,6 +295,8 @@ struct MarchParams {
     Geom g;
     unsigned lat_bytes;        // bytes of one lattice (9 planes) — below 4 GiB
     int nwin_total;            // windows per column
+    int win_stride = 0;        // k_march3: rows from one window to the next (0: the window height, 64 S — windows that tile the column and take the rows
+    int win_off = 0;           // beyond their seams out of the halo lines); OVERLAPPING windows (stride 64 S - 8, offset -4): see k_march3
     FastDiv fdv;               // fp32: tau and RN(1/tau)
     T tau;
     T U0;
@@ -390,6 +395,30 @@ template <int P, typename T, int S> __device__ __forceinline__ MV<T, S> m_above_
     for (int v = 0; v < S - 1; v++) o.v[v] = r.v[v + 1];
     o.v[S - 1] = shift_above_h<P>(r.v[0], hv);
     return o;
+}
+// ... and for OVERLAPPING windows (OVL; k_march3): the first / last lane's row beyond the window is a margin row's input — don't-care —, so the wave
+// shift alone (that lane keeps its own value: finite) does, one data-parallel-primitive move per direction
+template <int N, bool OVL, typename T, int S> __device__ __forceinline__ MV<T, S> m_below_x(const MV<T, S> &r, T hv)
+{
+    if constexpr (!OVL) return m_below_h<N>(r, hv);
+    else {
+        MV<T, S> o;
+        o.v[0] = wave_up(r.v[S - 1]);
+#pragma unroll
+        for (int v = 1; v < S; v++) o.v[v] = r.v[v - 1];
+        return o;
+    }
+}
+template <int P, bool OVL, typename T, int S> __device__ __forceinline__ MV<T, S> m_above_x(const MV<T, S> &r, T hv)
+{
+    if constexpr (!OVL) return m_above_h<P>(r, hv);
+    else {
+        MV<T, S> o;
+#pragma unroll
+        for (int v = 0; v < S - 1; v++) o.v[v] = r.v[v + 1];
+        o.v[S - 1] = wave_down(r.v[0]);
+        return o;
+    }
 }
 
 // buffer addressing: rsrc = whole lattice; voff = the lane's byte offset (j0 * sizeof(T), loop-invariant);
@@ -523,13 +552,21 @@ template <int S> __device__ __forceinline__ uint32_t load_site_bytes(const uint8
 // column cost 3.2 plain ones).  Fetched ONE ITERATION AHEAD for every column of a general unit, beside the prefetched populations, and
 // handed down from level to level in registers, they cost two byte loads per iteration and no wait of their own.
 struct SiteBytes { uint32_t v[2]; };     // {solid4, code4}
-template <typename T, int S>
+// the row a lane's mask / bounce-code bytes are fetched from: its own first row, or — the margin lanes of an overlapping window below row 0 or beyond
+// the last row (k_march3), whose results nobody stores — the nearest rows that exist
+template <int S, bool OVL> __device__ __forceinline__ int site_row(int j0, int ny)
+{
+    if constexpr (OVL) return j0 < 0 ? 0 : (j0 > ny - S ? ny - S : j0);
+    else return j0;
+}
+template <typename T, int S, bool OVL = false>
 __device__ __forceinline__ SiteBytes site_bytes_load(const MarchParams<T> &p, int col, int j0)
 {
     const int c = col < 0 ? 0 : (col > p.g.nxl - 1 ? p.g.nxl - 1 : col);       // (columns outside carry no class: their bytes are never used)
+    const int jb = site_row<S, OVL>(j0, p.g.ny);
     SiteBytes r;
-    r.v[0] = load_site_bytes<S>(p.mask + (long)(c + 1) * p.g.pitch + j0);
-    r.v[1] = load_site_bytes<S>(p.bcode + (long)c * p.g.pitch + j0);
+    r.v[0] = load_site_bytes<S>(p.mask + (long)(c + 1) * p.g.pitch + jb);
+    r.v[1] = load_site_bytes<S>(p.bcode + (long)c * p.g.pitch + jb);
     return r;
 }
 
@@ -873,11 +910,17 @@ template <typename T> __device__ __forceinline__ T halo_load(__amdgpu_buffer_rsr
 
 // march_load_aligned's inputs of one column -> the streamed (pulled) inputs: populations 2,5,6 come from one row below, 4,7,8 from one row above;
 // `hv` = the column's halo words, level 0 in lanes 12..14 (from below) and 60..62 (from above)
-template <typename T, int S>
+template <bool OVL = false, typename T, int S>
 __device__ __forceinline__ void march_align_in(MV<T, S> (&in)[9], int lane, T hv)
 {
-    in[2] = m_below_h<12>(in[2], hv); in[5] = m_below_h<13>(in[5], hv); in[6] = m_below_h<14>(in[6], hv);
-    in[4] = m_above_h<12>(in[4], hv); in[7] = m_above_h<13>(in[7], hv); in[8] = m_above_h<14>(in[8], hv);
+    in[2] = m_below_x<12, OVL>(in[2], hv); in[5] = m_below_x<13, OVL>(in[5], hv); in[6] = m_below_x<14, OVL>(in[6], hv);
+    in[4] = m_above_x<12, OVL>(in[4], hv); in[7] = m_above_x<13, OVL>(in[7], hv); in[8] = m_above_x<14, OVL>(in[8], hv);
+}
+// a column's halo line — none for overlapping windows
+template <bool OVL, typename T> __device__ __forceinline__ T halo_load_x(__amdgpu_buffer_rsrc_t rh, unsigned hoff, unsigned soff)
+{
+    if constexpr (OVL) return T(0);
+    else return halo_load<T>(rh, hoff, soff);
 }
 
 // ---- a general column's OWN populations, prefetched into LDS (round 5) ----
@@ -894,13 +937,13 @@ __device__ __forceinline__ void march_align_in(MV<T, S> (&in)[9], int lane, T hv
 // workgroup of solo units does not use.
 static constexpr int OWN_LDS_BYTES = 9 * 512;      // one buffer: nine populations x 512 bytes
 typedef __attribute__((address_space(3))) void *lds_void_p;
-template <typename T, int S>
+template <typename T, int S, bool OVL = false>
 __device__ __forceinline__ void own_prefetch(const MarchAddr<T, S> &a, int col, char *buf)
 {
     static_assert(64 * S * sizeof(T) == 512, "one population of a window's column is 512 bytes");
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        const unsigned soff = lat_off(a, k, col, 0);
+        const unsigned soff = lat_off(a, k, col, 0) - (OVL ? 256u : 0u);      // (OVL: a.voff_dma is kept 256 bytes high, k_march3)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rs, (lds_void_p)(buf + 512 * k), 4, a.voff_dma, soff, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rs, (lds_void_p)(buf + 512 * k), 4, a.voff_dma, soff, 256, 0);
     }
@@ -940,8 +983,8 @@ __device__ __forceinline__ void march_step1(const MarchParams<T> &p, const March
             if (nonfast) {
                 if (pre) { solid4 = pre[0]; code4 = pre[1]; }
                 else {
-                    solid4 = load_site_bytes<S>(p.mask + (long)(x + 1) * g.pitch + j0);
-                    code4 = load_site_bytes<S>(p.bcode + (long)x * g.pitch + j0);
+                    solid4 = load_site_bytes<S>(p.mask + (long)(x + 1) * g.pitch + site_row<S, (FD & MARCH_FD_OVL) != 0>(j0, g.ny));
+                    code4 = load_site_bytes<S>(p.bcode + (long)x * g.pitch + site_row<S, (FD & MARCH_FD_OVL) != 0>(j0, g.ny));
                 }
             }
             const bool any_solid = __ballot(solid4 != 0) != 0ULL;

@@ -385,11 +385,12 @@ __device__ __forceinline__ void march_stage(const MarchParams<T> &p, int c, int 
 {
     typedef MV<T, S> V3;
     const Geom &g = p.g;
+    constexpr bool OVL = (FD & MARCH_FD_OVL) != 0;
     // `hv` = this lane's element of column c's halo words, LB = 4 (level - 1): the lane of the level's first from-below word (from above: 48 + LB)
     V3 fin[9];
     fin[0] = Gc[0]; fin[1] = m158[0]; fin[3] = Gn[3];
-    fin[2] = m_below_h<LB>(Gc[2], hv); fin[5] = m_below_h<LB + 1>(m158[1], hv); fin[6] = m_below_h<LB + 2>(Gn[6], hv);
-    fin[4] = m_above_h<LB>(Gc[4], hv); fin[8] = m_above_h<LB + 2>(m158[2], hv); fin[7] = m_above_h<LB + 1>(Gn[7], hv);
+    fin[2] = m_below_x<LB, OVL>(Gc[2], hv); fin[5] = m_below_x<LB + 1, OVL>(m158[1], hv); fin[6] = m_below_x<LB + 2, OVL>(Gn[6], hv);
+    fin[4] = m_above_x<LB, OVL>(Gc[4], hv); fin[8] = m_above_x<LB + 2, OVL>(m158[2], hv); fin[7] = m_above_x<LB + 1, OVL>(Gn[7], hv);
     if (BODY) {
         const int gi = c + g.gi0;
         if (__builtin_expect(gi <= 0 || nf, 0)) {
@@ -398,8 +399,8 @@ __device__ __forceinline__ void march_stage(const MarchParams<T> &p, int c, int 
             if (nf) {
                 if (pre) { solid4 = pre[0]; code4 = pre[1]; }
                 else {
-                    solid4 = load_site_bytes<S>(p.mask + (long)(c + 1) * g.pitch + j0);
-                    code4 = load_site_bytes<S>(p.bcode + (long)c * g.pitch + j0);
+                    solid4 = load_site_bytes<S>(p.mask + (long)(c + 1) * g.pitch + site_row<S, OVL>(j0, g.ny));
+                    code4 = load_site_bytes<S>(p.bcode + (long)c * g.pitch + site_row<S, OVL>(j0, g.ny));
                 }
             }
             const bool any_solid = __ballot(solid4 != 0) != 0ULL;
@@ -427,7 +428,7 @@ __device__ __forceinline__ void march_stage(const MarchParams<T> &p, int c, int 
 // seams in LDS (the first 4/S lanes hold rows 0..3, the last 4/S lanes the last four rows; every lane writes its 8 bytes
 // — the others into a scratch area)
 // (`voff_st`: the lane's store offset, or an out-of-range one to drop the column's stores without a branch)
-template <bool EMIT, typename T, int S>
+template <bool EMIT, bool OVL = false, typename T, int S>
 __device__ __forceinline__ void march3_store(const March3Addr<T, S> &m, unsigned voff_st, int col, const MV<T, S> (&out)[9], const MV<T, S> (&mac)[3])
 {
     const MarchAddr<T, S> &a = m.a;
@@ -438,11 +439,13 @@ __device__ __forceinline__ void march3_store(const March3Addr<T, S> &m, unsigned
 #pragma unroll
         for (int q = 0; q < 3; q++) (void)bstore<T, S>(a.rm, voff_st, (unsigned)q * a.mp4 + mo, mac[q]);
     }
+    if constexpr (!OVL) {            // (overlapping windows keep no seam buffer)
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        u2v x;
-        __builtin_memcpy(&x, &out[k], 8);
-        *reinterpret_cast<u2v *>(m.lds_w + 4 * k) = x;
+        for (int k = 0; k < 9; k++) {
+            u2v x;
+            __builtin_memcpy(&x, &out[k], 8);
+            *reinterpret_cast<u2v *>(m.lds_w + 4 * k) = x;
+        }
     }
 }
 // Make the wait for the prefetched column land HERE (an empty asm that reads its 18 registers), before this iteration's
@@ -492,17 +495,19 @@ __device__ __forceinline__ void pin_after(const MV<T, S> (&c)[9])
     asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(r[4]), "v"(r[5]), "v"(r[6]), "v"(r[7]), "v"(r[8]));
 }
 struct Seam3 { u4v below, above; };      // one 16-byte chunk of each staged half
-template <typename T, int S>
+template <bool OVL = false, typename T, int S>
 __device__ __forceinline__ Seam3 seam3_fetch(const March3Addr<T, S> &m)
 {
     Seam3 r;
+    if constexpr (OVL) { r.below = u4v{0, 0, 0, 0}; r.above = r.below; return r; }
     r.below = *reinterpret_cast<const u4v *>(m.lds_r);                                      // the window's last four rows
     r.above = *reinterpret_cast<const u4v *>(m.lds_r + M3_SHALF * sizeof(T));              // rows 0..3
     return r;
 }
-template <typename T, int S>
+template <bool OVL = false, typename T, int S>
 __device__ __forceinline__ void seam3_flush(const March3Addr<T, S> &m, int col, const Seam3 &r)
 {
+    if constexpr (OVL) return;
     const unsigned so = (unsigned)(col + 1) * (unsigned)(M3_SREC * sizeof(T));
     const u4v d0 = r.below, d1 = r.above;
     __builtin_amdgcn_raw_buffer_store_b128(d0, m.rs3, m.voff_hi, so, 0);        // -> seam w+1, half 0
@@ -515,6 +520,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
                                             int ia, int ib, int uflags, int j0, int lane, bool far_win, ClassMask nonfast_m,
                                             ClassMask solid_m, const T (&feq0)[9])
 {
+    constexpr bool OVLF = (FD & MARCH_FD_OVL) != 0;      // overlapping windows: no halo lines, no seam rows (step_chain.hpp k_march3)
     typedef MV<T, S> V3;
     constexpr unsigned HREC = M3_HL * sizeof(T);     // bytes of one halo line
     const Geom &g = p.g;
@@ -524,7 +530,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     // a general column's own populations come out of this wave's LDS buffer (x & 1) (step_march.hpp own_prefetch): requested one iteration ahead in
     // the loop, on the spot (OWN_NOW) for the unit's first columns
 #define OWN_BUF(x) (a.own_lds + ((x) & 1) * OWN_LDS_BYTES)
-#define OWN_NOW(x) do { if (BODY && NONFAST(x)) own_prefetch<T, S>(a, (x), OWN_BUF(x)); } while (0)
+#define OWN_NOW(x) do { if (BODY && NONFAST(x)) own_prefetch<T, S, OVLF>(a, (x), OWN_BUF(x)); } while (0)
 #define STEP1(x, in, G) march_step1<BODY, FD, T, S, BODY>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, nullptr, OWN_BUF(x))
 #define STEP1P(x, in, G, sb) march_step1<BODY, FD, T, S, BODY>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, BODY ? (sb).v : nullptr, OWN_BUF(x))
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
@@ -540,27 +546,27 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
     s2m[0] = s1c[1]; s2m[1] = s1c[5]; s2m[2] = s1c[8];
     // halo lines of the columns the first iteration's stages work on (afterwards: one line per iteration, fetched one iteration ahead like the
     // populations, and handed from stage to stage)
-    T hv2 = halo_load<T>(rh, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * HREC);          // column x-2
-    T hv1 = halo_load<T>(rh, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);          // column x-1
-    T hv0 = halo_load<T>(rh, hoff, (unsigned)ia * HREC);                                 // column x
+    T hv2 = halo_load_x<OVLF, T>(rh, hoff, (unsigned)(ia - 2 > 0 ? ia - 2 : 0) * HREC);          // column x-2
+    T hv1 = halo_load_x<OVLF, T>(rh, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC);          // column x-1
+    T hv0 = halo_load_x<OVLF, T>(rh, hoff, (unsigned)ia * HREC);                                 // column x
     if (!BODY || ia - 2 + g.gi0 >= 0) {
         OWN_NOW(ia - 2);
         march_load_aligned(a, ia - 2, in);
-        march_align_in(in, lane, hv2);
+        march_align_in<OVLF>(in, lane, hv2);
         STEP1(ia - 2, in, s1c);
     }
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     if (!BODY || ia - 1 + g.gi0 >= 0) {
         OWN_NOW(ia - 1);
         march_load_aligned(a, ia - 1, in);
-        march_align_in(in, lane, hv1);
+        march_align_in<OVLF>(in, lane, hv1);
         STEP1(ia - 1, in, s1c);
     }
     OWN_NOW(ia);
     march_load_aligned(a, ia, in);
     // site bytes of columns x, x-1, x-2 (general loop only; see SiteBytes)
     SiteBytes sb0{{0, 0}}, sb1{{0, 0}}, sb2{{0, 0}};
-    if (BODY) { sb0 = site_bytes_load<T, S>(p, ia, j0); sb1 = site_bytes_load<T, S>(p, ia - 1, j0); sb2 = site_bytes_load<T, S>(p, ia - 2, j0); wait_for_bytes(sb0); wait_for_bytes(sb1); wait_for_bytes(sb2); }
+    if (BODY) { sb0 = site_bytes_load<T, S, OVLF>(p, ia, j0); sb1 = site_bytes_load<T, S, OVLF>(p, ia - 1, j0); sb2 = site_bytes_load<T, S, OVLF>(p, ia - 2, j0); wait_for_bytes(sb0); wait_for_bytes(sb1); wait_for_bytes(sb2); }
     wait_for_column(in, hv0, hv1, hv2);      // no load pending at the loop header: see wait_for_column
     int seam_col = -1;           // column whose seam rows are staged in LDS (-1: none yet; the flush then lands on the pad record)
 #ifdef WT_M3_STAMPS
@@ -574,16 +580,16 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         V3 nxt[9];
         // a general column next: its own populations on their way into LDS (own_prefetch), AHEAD of this iteration's prefetch — loads return in
         // order, so the wait for the prefetched column at the end of the iteration covers them (behind stage 1 instead: the plain slabs ran 4 % slower)
-        if (BODY && x + 1 <= xend && NONFAST(x + 1)) own_prefetch<T, S>(a, x + 1, OWN_BUF(x + 1));
+        if (BODY && x + 1 <= xend && NONFAST(x + 1)) own_prefetch<T, S, OVLF>(a, x + 1, OWN_BUF(x + 1));
         march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);              // prefetch (last one: harmless re-load)
         const bool has2 = x - 2 >= ia;                                         // column x-2 is an output column
         const int c1 = x - 1, c2 = x - 2;
-        const T hvn = halo_load<T>(rh, hoff, (unsigned)(x + 1) * HREC);        // column x+1's halo line: the next iteration's first stage
+        const T hvn = halo_load_x<OVLF, T>(rh, hoff, (unsigned)(x + 1) * HREC);        // column x+1's halo line: the next iteration's first stage
         SiteBytes sbn{{0, 0}};
-        if (BODY) sbn = site_bytes_load<T, S>(p, x + 1, j0);
-        const Seam3 sp = seam3_fetch(m);                                       // staged by the previous iteration's store
+        if (BODY) sbn = site_bytes_load<T, S, OVLF>(p, x + 1, j0);
+        const Seam3 sp = seam3_fetch<OVLF>(m);                                       // staged by the previous iteration's store
         M3_STAMP(0);                                                           // issue of the prefetch
-        march_align_in(in, lane, hv0);
+        march_align_in<OVLF>(in, lane, hv0);
         STEP1P(x, in, G1, sb0);                                                // level 1 of column x
         M3_STAMP(1);
         // level 2 of column x-1 (a column left of the inlet takes the inlet branch: constants, no memory access)
@@ -603,8 +609,8 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
 #endif
         M3_STAMP(4);                                                           // the wait for the prefetched column
         hv2 = hv1; hv1 = hv0; hv0 = hvn;
-        march3_store<EMIT>(m, has2 ? a.voff_st : p.lat_bytes, has2 ? c2 : 0, out, mac);
-        seam3_flush(m, seam_col, sp);
+        march3_store<EMIT, OVLF>(m, has2 ? a.voff_st : p.lat_bytes, has2 ? c2 : 0, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         M3_STAMP(5);                                                           // issue of the stores
         seam_col = has2 ? c2 : seam_col;
         if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
@@ -626,7 +632,7 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         //   level 2 of NX-1 = level 1 of NX-2;  level 3 of NX-1 = level 2 of NX-2;  solid sites: own previous level reversed.
         const int co = ib;                                   // outlet column
         uint32_t solid4 = 0;
-        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + j0);
+        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + site_row<S, OVLF>(j0, g.ny));
         const bool any_solid = __ballot(solid4 != 0) != 0ULL;
         V3 L2o[9], out[9];
 #pragma unroll
@@ -635,23 +641,23 @@ __device__ __forceinline__ void march_unit3(const MarchParams<T> &p, March3Addr<
         // level 3 of column NX-2
         V3 t2m[3];
         t2m[0] = s2c[1]; t2m[1] = s2c[5]; t2m[2] = s2c[8];
-        const T hv2t = halo_load<T>(rh, hoff, (unsigned)(co - 1) * HREC);
-        Seam3 sp = seam3_fetch(m);
+        const T hv2t = halo_load_x<OVLF, T>(rh, hoff, (unsigned)(co - 1) * HREC);
+        Seam3 sp = seam3_fetch<OVLF>(m);
         march_stage<BODY, EMIT, FD, 4>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, t2m, G2, L2o, hv2t, out, mac);
-        march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
-        seam3_flush(m, seam_col, sp);
+        march3_store<EMIT, OVLF>(m, a.voff_st, co - 1, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         seam_col = co - 1;
         // level 3 of the outlet column
 #pragma unroll
         for (int k = 0; k < 9; k++) out[k] = G2[k];
         if (EMIT) march_outlet_macro(G2, mac);
         if (any_solid) { auto own2 = [&](int k) { return L2o[k]; }; march_solid<T, S, EMIT>(out, mac, solid4, own2); }
-        sp = seam3_fetch(m);
-        march3_store<EMIT>(m, a.voff_st, co, out, mac);
-        seam3_flush(m, seam_col, sp);
+        sp = seam3_fetch<OVLF>(m);
+        march3_store<EMIT, OVLF>(m, a.voff_st, co, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         seam_col = co;
     }
-    seam3_flush(m, seam_col, seam3_fetch(m));
+    seam3_flush<OVLF>(m, seam_col, seam3_fetch<OVLF>(m));
 #undef NONFAST
 #undef ALLSOLID
 #undef STEP1
@@ -668,6 +674,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
                                             unsigned hoff, int ia, int ib, int uflags, int j0, int lane, bool far_win,
                                             ClassMask nonfast_m, ClassMask solid_m, const T (&feq0)[9])
 {
+    constexpr bool OVLF = (FD & MARCH_FD_OVL) != 0;      // overlapping windows: no halo lines, no seam rows (step_chain.hpp k_march3)
     typedef MV<T, S> V3;
     constexpr unsigned HREC = M3_HL * sizeof(T);
     const Geom &g = p.g;
@@ -676,7 +683,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
 #define NONFAST(x) (BODY && (x) >= ia - 3 && cm_bit(nonfast_m, (x) - ia + 3))
 #define ALLSOLID(x) (BODY && (x) >= ia - 3 && cm_bit(solid_m, (x) - ia + 3))
 #define OWN_BUF(x) (a.own_lds + ((x) & 1) * OWN_LDS_BYTES)
-#define OWN_NOW(x) do { if (BODY && NONFAST(x)) own_prefetch<T, S>(a, (x), OWN_BUF(x)); } while (0)      // (see march_unit3)
+#define OWN_NOW(x) do { if (BODY && NONFAST(x)) own_prefetch<T, S, OVLF>(a, (x), OWN_BUF(x)); } while (0)      // (see march_unit3)
 #define STEP1(x, in, G) march_step1<BODY, FD, T, S, BODY>(p, a, (x), j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G, nullptr, OWN_BUF(x))
 #define HCOL(c) ((unsigned)((c) > 0 ? (c) : 0) * HREC)
     const bool outlet = BODY && (uflags & MU_OUTLET_AFTER) != 0;
@@ -694,19 +701,19 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     const int xs = ia - 1;       // first loop column; when it lies left of the inlet its loads go to the inlet column (values unused)
 #define LCOL(x) ((BODY && (x) + g.gi0 < 0) ? -g.gi0 : (x))
     // halo lines of columns x-3, x-2, x-1, x (afterwards: one line per iteration, fetched one iteration ahead, handed from stage to stage)
-    T hv3 = halo_load<T>(rh, hoff, HCOL(xs - 3)), hv2 = halo_load<T>(rh, hoff, HCOL(xs - 2)), hv1 = halo_load<T>(rh, hoff, HCOL(xs - 1)),
-      hv0 = halo_load<T>(rh, hoff, HCOL(xs));
+    T hv3 = halo_load_x<OVLF, T>(rh, hoff, HCOL(xs - 3)), hv2 = halo_load_x<OVLF, T>(rh, hoff, HCOL(xs - 2)), hv1 = halo_load_x<OVLF, T>(rh, hoff, HCOL(xs - 1)),
+      hv0 = halo_load_x<OVLF, T>(rh, hoff, HCOL(xs));
     if (!BODY || ia - 3 + g.gi0 >= 0) {
         OWN_NOW(ia - 3);
         march_load_aligned(a, ia - 3, in);
-        march_align_in(in, lane, hv2);          // ia - 3 = xs - 2
+        march_align_in<OVLF>(in, lane, hv2);          // ia - 3 = xs - 2
         STEP1(ia - 3, in, s1c);
     }
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
     if (!BODY || ia - 2 + g.gi0 >= 0) {
         OWN_NOW(ia - 2);
         march_load_aligned(a, ia - 2, in);
-        march_align_in(in, lane, hv1);          // ia - 2 = xs - 1
+        march_align_in<OVLF>(in, lane, hv1);          // ia - 2 = xs - 1
         STEP1(ia - 2, in, s1c);
     }
     OWN_NOW(xs);                                // (a column left of the inlet carries no class)
@@ -714,7 +721,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
     // site bytes of columns x, x-1, x-2, x-3 (general loop only; see SiteBytes)
     SiteBytes sb0{{0, 0}}, sb1{{0, 0}}, sb2{{0, 0}}, sb3{{0, 0}};
     if (BODY) {
-        sb0 = site_bytes_load<T, S>(p, xs, j0); sb1 = site_bytes_load<T, S>(p, xs - 1, j0); sb2 = site_bytes_load<T, S>(p, xs - 2, j0); sb3 = site_bytes_load<T, S>(p, xs - 3, j0);
+        sb0 = site_bytes_load<T, S, OVLF>(p, xs, j0); sb1 = site_bytes_load<T, S, OVLF>(p, xs - 1, j0); sb2 = site_bytes_load<T, S, OVLF>(p, xs - 2, j0); sb3 = site_bytes_load<T, S, OVLF>(p, xs - 3, j0);
         wait_for_bytes(sb0); wait_for_bytes(sb1); wait_for_bytes(sb2); wait_for_bytes(sb3);
     }
     wait_for_column(in, hv0, hv1, hv2);
@@ -723,15 +730,15 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
 #pragma unroll 1
     for (int x = xs; x <= xend; x++) {
         V3 nxt[9];
-        if (BODY && x + 1 <= xend && NONFAST(x + 1)) own_prefetch<T, S>(a, x + 1, OWN_BUF(x + 1));      // (see march_unit3)
+        if (BODY && x + 1 <= xend && NONFAST(x + 1)) own_prefetch<T, S, OVLF>(a, x + 1, OWN_BUF(x + 1));      // (see march_unit3)
         march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has3 = x - 3 >= ia;                                         // column x-3 is an output column
         const int c1 = x - 1, c2 = x - 2, c3 = x - 3;
-        const T hvn = halo_load<T>(rh, hoff, HCOL(x + 1));                      // column x+1's halo line: the next iteration's first stage
+        const T hvn = halo_load_x<OVLF, T>(rh, hoff, HCOL(x + 1));                      // column x+1's halo line: the next iteration's first stage
         SiteBytes sbn{{0, 0}};
-        if (BODY) sbn = site_bytes_load<T, S>(p, x + 1, j0);
-        const Seam3 sp = seam3_fetch(m);
-        march_align_in(in, lane, hv0);
+        if (BODY) sbn = site_bytes_load<T, S, OVLF>(p, x + 1, j0);
+        const Seam3 sp = seam3_fetch<OVLF>(m);
+        march_align_in<OVLF>(in, lane, hv0);
         march_step1<BODY, FD, T, S, BODY>(p, a, x, j0, far_win, NONFAST(x), ALLSOLID(x), feq0, in, G1, BODY ? sb0.v : nullptr, OWN_BUF(x));      // level 1 of column x
 
         march_stage<BODY, false, FD, 0>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, G2, mac, BODY ? sb1.v : nullptr);     // level 2 of x-1
@@ -742,8 +749,8 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         wait_for_column(nxt, hvn);
         if (BODY) { wait_for_bytes(sbn); sb3 = sb2; sb2 = sb1; sb1 = sb0; sb0 = sbn; }
         hv3 = hv2; hv2 = hv1; hv1 = hv0; hv0 = hvn;
-        march3_store<EMIT>(m, has3 ? a.voff_st : p.lat_bytes, has3 ? c3 : 0, out, mac);
-        seam3_flush(m, seam_col, sp);
+        march3_store<EMIT, OVLF>(m, has3 ? a.voff_st : p.lat_bytes, has3 ? c3 : 0, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         seam_col = has3 ? c3 : seam_col;
         if (BODY && outlet && x == xend) break;                                // the tail below needs the unshifted state
         s3m[0] = s3c[1]; s3m[1] = s3c[5]; s3m[2] = s3c[8];
@@ -758,7 +765,7 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         // sites: own level k reversed.
         const int co = ib;
         uint32_t solid4 = 0;
-        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + j0);
+        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + site_row<S, OVLF>(j0, g.ny));
         const bool any_solid = __ballot(solid4 != 0) != 0ULL;
         V3 O2[9], O3[9], L3a[9], out[9], tm[3];
         // level 2 of co
@@ -767,38 +774,38 @@ __device__ __forceinline__ void march_unit4(const MarchParams<T> &p, March3Addr<
         if (any_solid) { auto own = [&](int k) { return G1[k]; }; march_solid<T, S, false>(O2, mac, solid4, own); }
         // level 3 of co-1
         tm[0] = s2c[1]; tm[1] = s2c[5]; tm[2] = s2c[8];
-        march_stage<BODY, false, FD, 4>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, G2, O2, halo_load<T>(rh, hoff, HCOL(co - 1)), L3a, mac);
+        march_stage<BODY, false, FD, 4>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, G2, O2, halo_load_x<OVLF, T>(rh, hoff, HCOL(co - 1)), L3a, mac);
         // level 3 of co
 #pragma unroll
         for (int k = 0; k < 9; k++) O3[k] = G2[k];
         if (any_solid) { auto own = [&](int k) { return O2[k]; }; march_solid<T, S, false>(O3, mac, solid4, own); }
         // level 4 of co-2
         tm[0] = s3c[1]; tm[1] = s3c[5]; tm[2] = s3c[8];
-        Seam3 sp = seam3_fetch(m);
+        Seam3 sp = seam3_fetch<OVLF>(m);
         // (a last unit of a single marched column does not own column co-2, and its level 3 of co-3 is not valid: drop the stores)
         const bool own2 = co - 2 >= ia;
-        march_stage<BODY, EMIT, FD, 8>(p, co - 2, j0, lane, far_win, NONFAST(co - 2), ALLSOLID(co - 2), feq0, tm, G3, L3a, halo_load<T>(rh, hoff, HCOL(co - 2)), out, mac);
-        march3_store<EMIT>(m, own2 ? a.voff_st : p.lat_bytes, own2 ? co - 2 : 0, out, mac);
-        seam3_flush(m, seam_col, sp);
+        march_stage<BODY, EMIT, FD, 8>(p, co - 2, j0, lane, far_win, NONFAST(co - 2), ALLSOLID(co - 2), feq0, tm, G3, L3a, halo_load_x<OVLF, T>(rh, hoff, HCOL(co - 2)), out, mac);
+        march3_store<EMIT, OVLF>(m, own2 ? a.voff_st : p.lat_bytes, own2 ? co - 2 : 0, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         seam_col = own2 ? co - 2 : seam_col;
         // level 4 of co-1
         tm[0] = G3[1]; tm[1] = G3[5]; tm[2] = G3[8];
-        sp = seam3_fetch(m);
-        march_stage<BODY, EMIT, FD, 8>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, L3a, O3, halo_load<T>(rh, hoff, HCOL(co - 1)), out, mac);
-        march3_store<EMIT>(m, a.voff_st, co - 1, out, mac);
-        seam3_flush(m, seam_col, sp);
+        sp = seam3_fetch<OVLF>(m);
+        march_stage<BODY, EMIT, FD, 8>(p, co - 1, j0, lane, far_win, NONFAST(co - 1), ALLSOLID(co - 1), feq0, tm, L3a, O3, halo_load_x<OVLF, T>(rh, hoff, HCOL(co - 1)), out, mac);
+        march3_store<EMIT, OVLF>(m, a.voff_st, co - 1, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         seam_col = co - 1;
         // level 4 of co
 #pragma unroll
         for (int k = 0; k < 9; k++) out[k] = L3a[k];
         if (EMIT) march_outlet_macro(L3a, mac);
         if (any_solid) { auto own = [&](int k) { return O3[k]; }; march_solid<T, S, EMIT>(out, mac, solid4, own); }
-        sp = seam3_fetch(m);
-        march3_store<EMIT>(m, a.voff_st, co, out, mac);
-        seam3_flush(m, seam_col, sp);
+        sp = seam3_fetch<OVLF>(m);
+        march3_store<EMIT, OVLF>(m, a.voff_st, co, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         seam_col = co;
     }
-    seam3_flush(m, seam_col, seam3_fetch(m));
+    seam3_flush<OVLF>(m, seam_col, seam3_fetch<OVLF>(m));
 #undef NONFAST
 #undef ALLSOLID
 #undef STEP1
@@ -815,6 +822,7 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Ad
                                                int uflags, int j0, int lane, bool far_win, ClassMask nonfast_m, ClassMask solid_m,
                                                const T (&feq0)[9])
 {
+    constexpr bool OVLF = (FD & MARCH_FD_OVL) != 0;      // overlapping windows: no halo lines, no seam rows (step_chain.hpp k_march3)
     typedef MV<T, S> V3;
     constexpr unsigned HREC = M3_HL * sizeof(T);
     const Geom &g = p.g;
@@ -829,10 +837,10 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Ad
 #pragma unroll
     for (int k = 0; k < 9; k++) s1c[k] = mv_splat<T, S>(feq0[k]);
     s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
-    T hv1 = halo_load<T>(rh, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC), hv0 = halo_load<T>(rh, hoff, (unsigned)ia * HREC);
+    T hv1 = halo_load_x<OVLF, T>(rh, hoff, (unsigned)(ia - 1 > 0 ? ia - 1 : 0) * HREC), hv0 = halo_load_x<OVLF, T>(rh, hoff, (unsigned)ia * HREC);
     if (!BODY || ia - 1 + g.gi0 >= 0) {
         march_load_aligned(a, ia - 1, in);
-        march_align_in(in, lane, hv1);
+        march_align_in<OVLF>(in, lane, hv1);
         STEP1(ia - 1, in, s1c);
     }
     march_load_aligned(a, ia, in);
@@ -844,17 +852,17 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Ad
         march_load_aligned(a, (x + 1 <= xend) ? x + 1 : x, nxt);
         const bool has1 = x - 1 >= ia;                                         // column x-1 is an output column
         const int c1 = x - 1;
-        const T hvn = halo_load<T>(rh, hoff, (unsigned)(x + 1) * HREC);
-        const Seam3 sp = seam3_fetch(m);
-        march_align_in(in, lane, hv0);
+        const T hvn = halo_load_x<OVLF, T>(rh, hoff, (unsigned)(x + 1) * HREC);
+        const Seam3 sp = seam3_fetch<OVLF>(m);
+        march_align_in<OVLF>(in, lane, hv0);
         STEP1(x, in, G1);
         V3 out[9];
         march_stage<BODY, EMIT, FD, 0>(p, c1, j0, lane, far_win, NONFAST(c1), ALLSOLID(c1), feq0, s1m, s1c, G1, hv1, out, mac);
         pin_after(out);
         wait_for_column(nxt, hvn);
         hv1 = hv0; hv0 = hvn;
-        march3_store<EMIT>(m, has1 ? a.voff_st : p.lat_bytes, has1 ? c1 : 0, out, mac);
-        seam3_flush(m, seam_col, sp);
+        march3_store<EMIT, OVLF>(m, has1 ? a.voff_st : p.lat_bytes, has1 ? c1 : 0, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         seam_col = has1 ? c1 : seam_col;
         if (BODY && outlet && x == xend) break;
         s1m[0] = s1c[1]; s1m[1] = s1c[5]; s1m[2] = s1c[8];
@@ -865,18 +873,18 @@ __device__ __forceinline__ void march_unit3_d2(const MarchParams<T> &p, March3Ad
         // x = ib = NX-1: s1c = level 1 of NX-2, G1 = level 1 of NX-1; level 2 of the outlet column = level 1 of NX-2 (html:301-312)
         const int co = ib;
         uint32_t solid4 = 0;
-        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + j0);
+        if (NONFAST(co)) solid4 = load_site_bytes<S>(p.mask + (long)(co + 1) * g.pitch + site_row<S, OVLF>(j0, g.ny));
         V3 out[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) out[k] = s1c[k];
         if (EMIT) march_outlet_macro(s1c, mac);
         if (__ballot(solid4 != 0) != 0ULL) { auto own1 = [&](int k) { return G1[k]; }; march_solid<T, S, EMIT>(out, mac, solid4, own1); }
-        const Seam3 sp = seam3_fetch(m);
-        march3_store<EMIT>(m, a.voff_st, co, out, mac);
-        seam3_flush(m, seam_col, sp);
+        const Seam3 sp = seam3_fetch<OVLF>(m);
+        march3_store<EMIT, OVLF>(m, a.voff_st, co, out, mac);
+        seam3_flush<OVLF>(m, seam_col, sp);
         seam_col = co;
     }
-    seam3_flush(m, seam_col, seam3_fetch(m));
+    seam3_flush<OVLF>(m, seam_col, seam3_fetch<OVLF>(m));
 #undef NONFAST
 #undef ALLSOLID
 #undef STEP1

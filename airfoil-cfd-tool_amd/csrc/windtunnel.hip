@@ -155,6 +155,8 @@ struct wt_handle {
     bool two_op = true;                  // option "fast_div_two_op": the four-step fp32 kernel divides by tau in two operations where proved (d2q9.hpp)
     bool fast_math = false;              // option "fast_math": contracted collision in the marching kernels (opt-in; tolerance, not bit-equality)
     bool chain = true;                   // option "chain": plain-fluid workgroups share their units' edge columns (step_chain.hpp)
+    int win_overlap = -1;                // option "window_overlap": -1 automatic (fp32 slabs), 0 windows that tile the column + halo lines, 1 overlapping windows
+    bool ovl = false;                    // the present plan's windows overlap (k_march3, step_chain.hpp): no halo lines, no halo kernel, no seam buffer in use
     int n_chain_units = 0;
     // the plan's units on the host, and their refinement by measured unit times (tune_fuse_plan)
     std::vector<MarchUnit> host_units;
@@ -534,7 +536,7 @@ static bool plan_by_time(const wt_handle *h)
 static void cut_units(wt_handle *h, const float *colw, MarchPlan *out, const MarchRange *range = nullptr)
 {
     const Geom &g = h->g;
-    const int depth = h->march_depth, win = 64 * h->march_s;
+    const int depth = h->march_depth, win = 64 * h->march_s - (h->ovl ? 8 : 0);      // (the planners want the rows from window to window: the window count)
     const long target = h->plan_target;
     const MarchRange r = range ? *range : (depth >= 3 ? march_range3(g, depth) : march_range(g));
     // four steps per pass: class masks cover ib - ia + 6 columns, and the last unit of a window marches at least two
@@ -602,7 +604,12 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     const Geom &g = h->g;
     const int win = 64 * sites;
     const size_t eb = h->dtype == WT_F32 ? 4 : 8;
-    const int nwin = march_nwin(g.ny, win);
+    // Overlapping windows (k_march3, step_chain.hpp: four margin rows on either side in place of the halo lines): 128 / 120 of the arithmetic for no
+    // halo kernel — 10 of the 58 us of a pass on a slab of an 8-way split of 4096^2, 21 of 307 on the whole lattice.  Automatic: the fp32 slabs of a
+    // split (and stand-alone handles that plan like one, plan_columns); fp64 windows would keep 56 rows of 64.
+    h->ovl = depth >= 3 && h->dtype == WT_F32 && !h->fast_math && (h->win_overlap > 0 || (h->win_overlap < 0 && (h->nranks > 1 || h->plan_columns > 0)));
+    const int wstride = h->ovl ? win - 8 : win, woff = h->ovl ? -4 : 0;
+    const int nwin = march_nwin(g.ny, wstride);
     const size_t wbytes = (size_t)nwin * (g.nxl + 2), cbytes = (size_t)(g.nxl + 2) * g.pitch;
     if (h->n_win != nwin || h->march_s != sites || h->march_depth != depth) free_march_tables(h);
     long long added = 0;
@@ -639,9 +646,9 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     h->march_s = sites;
     h->march_depth = depth;
     const long nt = (long)(g.nxl + 2) * nwin;
-    hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->wcls, g, nwin, win);
+    hipLaunchKernelGGL(k_classify_windows, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->wcls, g, nwin, win, wstride, woff);
     hipLaunchKernelGGL(k_bounce_codes, dim3(2048), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, h->bcode, g);
-    if (nwin > 1) {
+    if (nwin > 1 && !h->ovl) {
         const long nth = (long)(nwin - 1) * g.nxl;
         if (depth == 4)
             hipLaunchKernelGGL(k_seam_flags4, dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, h->s_compute, (const uint8_t *)h->mask, (const uint8_t *)h->bcode,
@@ -888,6 +895,13 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         h->chain = value != 0.0;
         return rebuild_fuse_plan(h);
     }
+    if (strcmp(name, "window_overlap") == 0) {
+        // -1 automatic, 0 windows that tile the column (halo lines), 1 overlapping windows (k_march3).  The same bits either way, and the sequence of
+        // passes does not depend on it (the steps per pass are chosen from the tiling windows' count): a rank's own affair, like `tune`.
+        if (!(value == -1.0 || value == 0.0 || value == 1.0)) return fail(WT_ERR_ARG, "window_overlap must be -1 (automatic), 0 or 1");
+        h->win_overlap = (int)value;
+        return rebuild_fuse_plan(h);
+    }
     if (strcmp(name, "plan_columns") == 0) {
         // a stand-alone handle that stands in for one slab of a split plans like that split's narrowest slab (distributed.measure_slab_cost)
         if (value < 0) return fail(WT_ERR_ARG, "plan_columns must be >= 0");
@@ -911,8 +925,10 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
     }
     if (strcmp(name, "fast_math") == 0) {
         if (value != 0.0 && h->dtype != WT_F32) return fail(WT_ERR_STATE, "fast_math is an fp32 option");
+        const bool was = h->fast_math;
         h->fast_math = value != 0.0;
-        return WT_OK;
+        // (the contracted kernels know no overlapping windows: a plan that has them is cut again, and the other way round)
+        return (was != h->fast_math && (h->ovl || h->win_overlap != 0)) ? rebuild_fuse_plan(h) : WT_OK;
     }
     return fail(WT_ERR_ARG, "unknown option '%s'", name);
 }
@@ -930,6 +946,7 @@ extern "C" int wt_get_option(const wt_handle *h, const char *name, double *value
     if (strcmp(name, "fuse_tiles_general") == 0) { *value = h->nonfast_tiles; return WT_OK; }   // window-tiles that take the body paths
     if (strcmp(name, "fast_div") == 0) { *value = h->fast_div ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "chain") == 0) { *value = h->chain ? 1.0 : 0.0; return WT_OK; }
+    if (strcmp(name, "window_overlap") == 0) { *value = h->fuse_ready ? (h->ovl ? 1.0 : 0.0) : (double)h->win_overlap; return WT_OK; }     // the present plan's layout
     if (strcmp(name, "fast_math") == 0) { *value = h->fast_math ? 1.0 : 0.0; return WT_OK; }
     if (strcmp(name, "chain_units") == 0) { *value = h->fuse_ready ? h->n_chain_units : 0; return WT_OK; }     // units that run in chain blocks
     if (strcmp(name, "plan_columns") == 0) { *value = h->plan_columns; return WT_OK; }
@@ -1439,6 +1456,8 @@ static void march3_params(wt_handle *h, double tau, double u0, MarchParams<T> &p
     p.g = g;
     p.lat_bytes = (unsigned)((size_t)9 * g.plane * sizeof(T));
     p.nwin_total = h->n_win;
+    p.win_stride = h->ovl ? 64 * h->march_s - 8 : 0;
+    p.win_off = h->ovl ? -4 : 0;
     p.fdv = fastdiv_params(h, tau);
     p.tau = (T)tau;
     p.U0 = (T)u0;
@@ -1452,7 +1471,7 @@ template <typename T, int S, int FD>
 static void launch_halo_lines(wt_handle *h, const MarchParams<T> &p, int use_seams, int xb0, int nbx, hipStream_t st)
 {
     const Geom &g = h->g;
-    if (h->n_win <= 1) return;
+    if (h->n_win <= 1 || h->ovl) return;      // (overlapping windows read no halo lines)
     const int all = (g.nxl + HL_COLS - 1) / HL_COLS;
     if (nbx < 0) { xb0 = 0; nbx = all; }
     if (xb0 < 0) { nbx += xb0; xb0 = 0; }
@@ -1467,31 +1486,38 @@ static void launch_halo_lines(wt_handle *h, const MarchParams<T> &p, int use_sea
                            (const uint8_t *)h->seam_plain, reinterpret_cast<T *>(h->hlines), g, h->n_win, use_seams, p.fdv, p.tau, p.U0, xb0, nbx);
 }
 
-// the marching kernel over p.units (depth = steps this pass advances, on the tables of h->march_depth)
+// the marching kernel over p.units (depth = steps this pass advances, on the tables of h->march_depth); `ovl`: the plan's windows overlap
+// (p.win_stride: the instantiations without halo lines and seam rows, fp32 only — build_fuse_plan plans no other)
+template <typename T, int S, int FD, int DEPTH>
+static void launch_march3_k(const MarchParams<T> &p, bool emit, hipStream_t st)
+{
+    const dim3 grid((unsigned)((p.nunits + 3) / 4));
+    if (emit) hipLaunchKernelGGL((k_march3<T, S, DEPTH, true, FD>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_march3<T, S, DEPTH, false, FD>), grid, dim3(256), 0, st, p);
+}
 template <typename T, int S, int FD>
 static int launch_march3(const MarchParams<T> &p, int depth, bool emit, bool two_op, hipStream_t st)
 {
     if (p.nunits <= 0) return WT_OK;
-    const dim3 grid((unsigned)((p.nunits + 3) / 4));
+    const bool ovl = p.win_stride > 0;
+    constexpr bool CAN_OVL = sizeof(T) == 4 && (FD & MARCH_FD_CONTRACTED) == 0;
+    if (ovl && !CAN_OVL) return fail(WT_ERR_STATE, "internal: overlapping windows planned for a kernel that has none");
     if (depth == 4) {
         // (fp32 with the IEEE division by tau: not built — 40-80 bytes of scratch per lane; set_tau_cap keeps such a call at three steps per pass)
         if constexpr (sizeof(T) == 4 && FD == 0) return fail(WT_ERR_STATE, "internal: four-step pass with the IEEE division");
         else if constexpr (sizeof(T) == 4 && FD == 1) {
             // the division by tau in two operations where the device has proved it for this tau (fastdiv_for), in three otherwise
-            if (two_op) {
-                if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD | MARCH_FD_TWOOP>), grid, dim3(256), 0, st, p);
-                else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD | MARCH_FD_TWOOP>), grid, dim3(256), 0, st, p);
-            } else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
+            if (ovl) { if (two_op) launch_march3_k<T, S, FD | MARCH_FD_TWOOP | MARCH_FD_OVL, 4>(p, emit, st); else launch_march3_k<T, S, FD | MARCH_FD_OVL, 4>(p, emit, st); }
+            else if (two_op) launch_march3_k<T, S, FD | MARCH_FD_TWOOP, 4>(p, emit, st);
+            else launch_march3_k<T, S, FD, 4>(p, emit, st);
         }
-        else if (emit) hipLaunchKernelGGL((k_march3<T, S, 4, true, FD>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_march3<T, S, 4, false, FD>), grid, dim3(256), 0, st, p);
+        else launch_march3_k<T, S, FD, 4>(p, emit, st);
     } else if (depth == 3) {
-        if (emit) hipLaunchKernelGGL((k_march3<T, S, 3, true, FD>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_march3<T, S, 3, false, FD>), grid, dim3(256), 0, st, p);
+        if constexpr (CAN_OVL) { if (ovl) { launch_march3_k<T, S, FD | MARCH_FD_OVL, 3>(p, emit, st); return WT_OK; } }
+        launch_march3_k<T, S, FD, 3>(p, emit, st);
     } else {
-        if (emit) hipLaunchKernelGGL((k_march3<T, S, 2, true, FD>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_march3<T, S, 2, false, FD>), grid, dim3(256), 0, st, p);
+        if constexpr (CAN_OVL) { if (ovl) { launch_march3_k<T, S, FD | MARCH_FD_OVL, 2>(p, emit, st); return WT_OK; } }
+        launch_march3_k<T, S, FD, 2>(p, emit, st);
     }
     return WT_OK;
 }

@@ -39,22 +39,26 @@ def _drive(pkg, g, options=None):
 # every kernel form meets the fixtures generated from html:283-360 directly: the single-step kernel (depth 0) and the marching
 # kernels with 2 / 3 / 4 steps per pass forced onto these small lattices (fuse_steps = 2), each with the proved fast division by
 # tau and with the IEEE one
-FORMS = [(d, fd) for d in (0, 2, 3, 4) for fd in (1, 0)]
+# ... and, round 5, the three- and four-step kernels on OVERLAPPING windows (window_overlap = 1: margins of four rows in place of the halo lines; fp32 — an
+# fp64 handle keeps windows that tile the column whatever the option says)
+FORMS = [(d, fd, 0) for d in (0, 2, 3, 4) for fd in (1, 0)] + [(d, fd, 1) for d in (3, 4) for fd in (1, 0)]
 
 
-@pytest.mark.parametrize("depth,fast_div", FORMS, ids=[f"depth{d}-fd{fd}" for d, fd in FORMS])
+@pytest.mark.parametrize("depth,fast_div,overlap", FORMS, ids=[f"depth{d}-fd{fd}" + ("-overlap" if o else "") for d, fd, o in FORMS])
 @pytest.mark.parametrize("path", RUNS_ALL, ids=[os.path.basename(p)[:-4] for p in RUNS_ALL])
-def test_gpu_reproduces_reference_shader_goldens(pkg, path, depth, fast_div):
+def test_gpu_reproduces_reference_shader_goldens(pkg, path, depth, fast_div, overlap):
     g = np.load(path)
     opts = [("fast_div", fast_div)]
     if depth:
-        opts += [("fuse_depth", depth), ("fuse_steps", 2)]
+        opts += [("fuse_depth", depth), ("fuse_steps", 2), ("window_overlap", overlap)]
     else:
         opts += [("fuse_steps", 0)]
     with _drive(pkg, g, opts) as wt:
         if depth:       # the forced plan must really be the one that ran (mask changes mid-run rebuild it in place)
             assert wt.engine.get_option("fuse_active") == 1.0 and wt.engine.get_option("fuse_depth") == depth
             assert wt.engine.get_option("single_steps") <= int(g["steps"]) // 2
+            if depth >= 3:
+                assert wt.engine.get_option("window_overlap") == (1.0 if overlap and str(g["mode"]) == "f32" else 0.0)
         rho, ux, uy = wt.read_macro()
         f = wt.read_f()
     # stated fp tolerance ...
