@@ -561,6 +561,31 @@ static void cut_units(wt_handle *h, const float *colw, MarchPlan *out, const Mar
     *out = std::move(pl);
 }
 
+// Workgroup k of a launch runs on XCD k mod 8 (each with its own L2).  The planners list the workgroups chunk-major — the windows of one column range
+// next to one another —, so dealt out round-robin two windows that are vertical neighbours never share an L2.  For OVERLAPPING windows that matters:
+// neighbours read one 128-byte line in common per population and column and write the two halves of another.  Here the list is cut into eight
+// contiguous runs and run x is dealt to the positions x, x + 8, x + 16 ...: every XCD gets a stretch of column ranges with all their windows.
+// (padded with empty workgroups to a multiple of eight; the reversed launch order of every other pass keeps the runs together)
+static void xcd_order(std::vector<MarchUnit> &units)
+{
+    const size_t nb = (units.size() + 3) / 4;
+    if (nb < 16) return;
+    const size_t L = (nb + 7) / 8;
+    std::vector<MarchUnit> out(L * 8 * 4, MarchUnit{0, 0, units.empty() ? 0 : units[0].w, 0});
+    for (size_t b = 0; b < nb; b++) {
+        const size_t x = b / L, q = b % L, i = 8 * q + x;
+        for (size_t k = 0; k < 4 && 4 * b + k < units.size(); k++) out[4 * i + k] = units[4 * b + k];
+    }
+    units.swap(out);
+}
+// On for plans with overlapping windows, i.e. slabs (profiles/r05_s_xcd_order.txt: stand-alone slabs of the 8-way split of 4096^2 12.4-12.6 against
+// 13.0-13.8 us per step plain, 13.9-14.7 against 14.7-14.9 over the body; windows that tile the column gain 2-4 % on a slab and lose on the whole lattice).
+static bool xcd_order_on(const wt_handle *h)
+{
+    static const int e = exp_env("WT_XCD_ORDER") ? atoi(exp_env("WT_XCD_ORDER")) : -1;
+    return e >= 0 ? e != 0 : h->ovl;
+}
+
 static int upload_units(wt_handle *h, const MarchPlan &plan_in)
 {
     // the chain-block invariant the kernel's LDS hand-over rests on, checked on every plan that reaches the device (sanitize_chain_plan,
@@ -577,6 +602,7 @@ static int upload_units(wt_handle *h, const MarchPlan &plan_in)
             for (size_t b = 0; b + 3 < pl.units.size(); b += 4)
                 if (pl.units[b].flags & MU_CHAIN) { pl.units[b + 1].flags = 0; break; }
     }
+    if (xcd_order_on(h)) xcd_order(pl.units);
     for (auto &tp : h->trim_plans) tp.valid = false;       // cut from the kept plan's costs: stale now
     for (auto &rp : h->renew_plans) rp.valid = false;
     h->n_chain_units = 0;
@@ -1423,6 +1449,7 @@ static int trim_plan_for(wt_handle *h, int v_after, const MarchUnit **units, int
             const int max_solo = (h->march_depth == 4 ? MARCH3_MAX_CHUNK - 3 : MARCH3_MAX_CHUNK) - 2;
             h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), g, h->march_depth, max_solo);
         }
+        if (xcd_order_on(h)) xcd_order(pl.units);
         const size_t total = pl.units.size();
         if (total > tp->cap) {
             if (tp->d_units) { HIP_TRY(hipFree(tp->d_units)); tp->d_units = nullptr; tp->cap = 0; }
@@ -1589,6 +1616,7 @@ static int renew_plan_for(wt_handle *h, int depth, wt_handle::RenewPlan **out)
             MarchPlan pl;
             cut_units(h, colw, &pl, &ri);
             if (!h->host_wcls.empty()) h->chain_downgrades += sanitize_chain_plan(pl, h->host_wcls.data(), g, h->march_depth, max_solo);
+            if (xcd_order_on(h)) xcd_order(pl.units);
             lists[0] = pl.units;
         }
         // the strips: a handful of columns per window.  They run AFTER the exchange, with nothing beside them: what counts is how long their slowest
