@@ -142,6 +142,16 @@ WT_API const char *wt_version(void);
  *       leaves gv - k of them exact; the columns beyond are not marched at all (their results could never be read) — one unit list per
  *       remaining depth, cut from the kept plan's column costs the first time it is needed.  Between two refreshes a slab with halo 17 marches
  *       12, 8, 4 and 0 ghost columns per side instead of 14 four times.  "trimmed_passes" counts the passes that ran on a trimmed list.
+ *   "window_overlap" (default -1 = automatic; fp32, three / four steps per pass): the layout of the marching kernels' 128-row windows.  0: windows
+ *       that TILE the column — the rows beyond a window's seams come, level by level, out of halo lines a halo kernel builds before every pass
+ *       from a seam buffer the pass before wrote.  1: OVERLAPPING windows — a window owns the 120 rows in its middle and carries four margin rows
+ *       on either side, which lose one row of validity per level and are never stored: no halo lines, no halo kernel, no seam buffer, 128 / 120
+ *       of the arithmetic, loads and stores that straddle cache lines; the workgroups of such a plan are dealt to the XCDs in contiguous runs
+ *       (vertical neighbours share an L2).  The same bits either way.  Automatic: the slabs of a split (and "plan_columns" stand-ins) overlap —
+ *       the halo kernel is a fixed 10 of the 58 us of a slab's pass: slowest real slab of the 8-way split of 4096^2 19.9 -> 17.5 us per step
+ *       (profiles/r05_t_slab_costs_cfg2_overlap.txt) —, whole lattices tile (4096^2: 77 us per step against 90-97 overlapping, bound by its line
+ *       traffic).  fp64 handles and "fast_math" always tile.  Rank-local: the steps per pass are chosen from the tiling windows' count either
+ *       way, so the sequence of passes does not depend on it.  wt_get_option reports the present plan's layout.
  *   "refresh" (default 0, slab handles): how the ghost columns are renewed.  0: by a SINGLE step (k_step) whose interior columns run beside the
  *       exchange, the two edge strips (the ghost columns + one owned column: a few microseconds) after it — the step runs at the un-fused rate
  *       and the pass after it builds its halo lines by the gather path.  1: by an exchange at a PASS BOUNDARY — nothing runs beside it, and every
@@ -166,7 +176,7 @@ WT_API const char *wt_version(void);
  *       Fingerprinted: nx, ny, nranks, halo, dtype, the split, fuse_steps, fuse_depth, fuse_chunk, chain, fast_div, fast_math, plan_columns,
  *       refresh, the device's resident wave slots, eligibility, mask set, the planner's outcome (plan ready, steps per pass, pass cap), steps
  *       done, exact ghost columns.  Deliberately rank-local, i.e. NOT compared: "tune" / WT_TUNE and the cut it measures (its trial passes
- *       exchange nothing), "trim_ghosts" (which ghost columns a rank bothers to march), "fast_div_two_op", "exchange_timing".
+ *       exchange nothing), "trim_ghosts" (which ghost columns a rank bothers to march), "fast_div_two_op", "window_overlap", "exchange_timing".
  *       0 is for tests that mix plans on purpose.  "agree_checks" counts the checks made.
  *   "exchange_timing" (default 0, slab handles): HIP events around every ghost exchange (comm stream) and around the interior kernel and the
  *       wait that follows it (compute stream); summed over the refresh steps since the option was set by "exchange_ms", "interior_ms",

@@ -71,6 +71,8 @@ def test_marching_loop_instruction_budget(isa_files):
         "_ZN2wt8k_march3IfLi2ELi4ELb0ELi17EEEvNS_11MarchParamsIT_EE": (1042, 814, 496, 90),
         "_ZN2wt8k_march3IfLi2ELi4ELb0ELi1EEEvNS_11MarchParamsIT_EE": (1078, 850, 532, 90),
         "_ZN2wt8k_march3IdLi1ELi4ELb0ELi1EEEvNS_11MarchParamsIT_EE": (1225, 1032, 0, 56),
+        # overlapping windows (FD bit 5; the slabs' kernel): no halo-line load, six data-parallel moves per stage instead of twelve, no seam rows — 985 / 785
+        "_ZN2wt8k_march3IfLi2ELi4ELb0ELi49EEEvNS_11MarchParamsIT_EE": (996, 794, 496, 90),
     }
     for sym, (ex_max, valu_max, pk_max, mov_max) in budget.items():
         name, lines = L.kernel_lines(f, sym)
@@ -84,8 +86,8 @@ def test_marching_loop_instruction_budget(isa_files):
             except (KeyError, IndexError):
                 continue
             tot = sum(cc.values())
-            if 700 < tot < 1300 and cc.get("vmem", 0) == 21 and (best is None or tot < sum(best.values())):
-                best = cc                      # the chain units' loop: 9 loads + 1 halo line + 9 stores + 2 seam stores
+            if 700 < tot < 1300 and cc.get("vmem", 0) == (18 if "ELi49E" in sym else 21) and (best is None or tot < sum(best.values())):
+                best = cc                      # the chain units' loop: 9 loads + 1 halo line + 9 stores + 2 seam stores (overlapping windows: 9 + 9)
         assert best is not None, f"no marching loop found in {sym}"
         valu = sum(v for k, v in best.items() if k.startswith("v_"))
         got = (sum(best.values()), valu, best.get("v_pk", 0), best.get("v_mov", 0))
