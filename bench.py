@@ -490,6 +490,7 @@ def local_slabs_main(args, wtpkg, mask, body_name):
                        "fuse_active": int(e.get_option("fuse_active")), "fuse_depth": int(e.get_option("fuse_depth")),
                        "pass_depth": int(e.get_option("pass_depth")), "passes": int(e.get_option("passes")),
                        "single_steps": int(e.get_option("single_steps")), "agree_checks": int(e.get_option("agree_checks")),
+                       "window_overlap": int(e.get_option("window_overlap")),
                        "chain_downgrades": int(e.get_option("chain_downgrades"))} for r, e in enumerate(es)],
             "local_slabs": {"device_ms_per_step": [m / args.steps for m in dev_ms], "sum_device_ms_per_step": sum(dev_ms) / args.steps,
                             "group_wall_ms_per_step": wall / args.steps * 1e3,
@@ -717,6 +718,7 @@ def main():
                     "fuse_active": int(eng.get_option("fuse_active")), "fuse_depth": int(eng.get_option("fuse_depth")),
                     "pass_depth": int(eng.get_option("pass_depth")), "passes": int(eng.get_option("passes")),
                     "single_steps": int(eng.get_option("single_steps")), "agree_checks": int(eng.get_option("agree_checks")),
+                    "window_overlap": int(eng.get_option("window_overlap")),      # 1: the slab marches overlapping windows (no halo kernel)
                     "chain_downgrades": int(eng.get_option("chain_downgrades"))}
         rank_report = [None] * world
         dist.all_gather_object(rank_report, mine_rep)
