@@ -554,6 +554,22 @@ static void cut_units(wt_handle *h, const float *colw, MarchPlan *out, const Mar
     static const double beta = exp_env("WT_BETA") ? atof(exp_env("WT_BETA")) : 1.25;
     static const int max_chain = exp_env("WT_MAX_CHAIN") ? atoi(exp_env("WT_MAX_CHAIN")) : 160;
     const ChainCost cc{over, tail, depth == 4 ? 2.0 : 1.4, depth == 4 ? 2.0 : 1.4, beta, 0.6, max_chain, alpha_solid};
+    // experiments (tools/r5_asym.py): the workgroups of the first half of the launch (dispatched first: one per CU, they win the issue arbitration of their SIMDs
+    // against the second half's) run ahead of the others — with a FIXED launch order (WT_MARCH_REV=0) the columns of the list's first half can be made cheaper
+    // and the others dearer by a factor 1 -+ gamma, so that the older units get the longer stretches
+    std::vector<float> asym;
+    if (const char *ea = exp_env("WT_ASYM")) {
+        const double gamma = atof(ea);
+        if (gamma > 0.0 && gamma < 0.9) {
+            const int ld = g.nxl + 2, nwin = h->n_win;
+            asym.assign((size_t)nwin * ld, 1.0f);
+            const double xs = r.i_begin + (r.i_end - r.i_begin) * (1.0 + gamma) / 2.0;
+            for (int w = 0; w < nwin; w++)
+                for (int x = -1; x <= g.nxl; x++)
+                    asym[(size_t)w * ld + x + 1] = (float)((x < xs ? 1.0 / (1.0 + gamma) : 1.0 / (1.0 - gamma)) * (colw ? colw[(size_t)w * ld + x + 1] : 1.0f));
+            colw = asym.data();
+        }
+    }
     MarchPlan pl = !by_time ? build_march_plan(h->host_wcls.data(), g, win, target, h->fuse_chunk, timed ? alpha : 4.0, &r, min_last, max_len, chain ? 4 : 1)
                    : chain  ? build_chain_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, depth, cc, colw)
                             : build_march_plan_timed(h->host_wcls.data(), g, win, target, alpha, r, min_last, max_len, over, tail, alpha_solid, colw);
@@ -1489,6 +1505,10 @@ static void march3_params(wt_handle *h, double tau, double u0, MarchParams<T> &p
     p.tau = (T)tau;
     p.U0 = (T)u0;
     p.rev = (int)(h->passes & 1);
+    {
+        static const int rev_mode = exp_env("WT_MARCH_REV") ? atoi(exp_env("WT_MARCH_REV")) : 2;     // experiments: 0 / 1 = fixed order
+        if (rev_mode == 0 || rev_mode == 1) p.rev = rev_mode;
+    }
     p.stuck = h->stuck_dev;
     p.units = h->d_units; p.nunits = h->n_units;
 }

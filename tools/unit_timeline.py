@@ -41,3 +41,13 @@ with pkg.Engine(nx, ny) as e:
     print("  units alive at t = 0, 2, 4 ... us: " + " ".join(str(v) for v in occ))
     blk = np.arange(n)[live] // 4
     print("  first start of workgroup k (dispatch order), us, every 32nd: " + " ".join(f"{st[blk == k].min():.1f}" for k in range(0, int(blk.max()) + 1, 32) if (blk == k).any()))
+    # older / younger: workgroup k runs on XCD k % 8; on its XCD it is number k // 8, and with two workgroups per CU the second 32 of an XCD's 64 share their
+    # CUs (and SIMDs) with the first 32.  Median duration and end of the units by that half (launch order as dispatched: odd passes run the list reversed).
+    dur = en - st
+    nblk = (n + 3) // 4
+    for rev in (0, 1):
+        pos = (nblk - 1 - blk) if rev else blk
+        first = (pos // 8) < 32
+        if first.any() and (~first).any():
+            print(f"  assuming {'reversed' if rev else 'forward'} dispatch: first-dispatched half: duration median {np.median(dur[first]):.1f} end median {np.median(en[first]):.1f} max {en[first].max():.1f};"
+                  f" second half: duration median {np.median(dur[~first]):.1f} end median {np.median(en[~first]):.1f} max {en[~first].max():.1f}")
