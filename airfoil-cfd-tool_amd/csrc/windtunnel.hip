@@ -190,6 +190,7 @@ struct wt_handle {
     // the pass" (the kept plan's range shrunk at the slab's local edges), cut lazily with the kept plan's measured column costs.
     struct TrimPlan { int v_after = -1; MarchUnit *d_units = nullptr; size_t cap = 0; int n_units = 0; bool valid = false; };
     std::vector<TrimPlan> trim_plans;
+    bool trim_prebuilt = false;          // the lists of the two standard cycles exist (prebuild_trim_plans)
     // refresh = 2 (renew_plan_for): per pass length, the unit lists of the interior columns [0] and of the two edge strips [1]
     struct RenewPlan { int depth = 0; MarchUnit *d_units[2] = {nullptr, nullptr}; size_t cap[2] = {0, 0}; int n_units[2] = {0, 0}; int strip_lo[2] = {0, 0}, strip_hi[2] = {0, 0}; bool valid = false; };
     std::vector<RenewPlan> renew_plans;
@@ -620,6 +621,7 @@ static int upload_units(wt_handle *h, const MarchPlan &plan_in)
     }
     if (xcd_order_on(h)) xcd_order(pl.units);
     for (auto &tp : h->trim_plans) tp.valid = false;       // cut from the kept plan's costs: stale now
+    h->trim_prebuilt = false;
     for (auto &rp : h->renew_plans) rp.valid = false;
     h->n_chain_units = 0;
     for (const MarchUnit &u : pl.units) h->n_chain_units += (u.flags & MU_CHAIN) != 0;
@@ -963,6 +965,7 @@ extern "C" int wt_set_option(wt_handle *h, const char *name, double value)
         if (!(value == 0.0 || value == 1.0 || value == 2.0))
             return fail(WT_ERR_ARG, "refresh must be 0 (overlapped single step), 1 (exchange at a pass boundary) or 2 (exchange beside the interior of a fused pass)");
         h->refresh_mode = (int)value;
+        h->trim_prebuilt = false;        // (mode 2's unit lists are cut with the others before the next stepping call)
         return WT_OK;
     }
     if (strcmp(name, "fast_math") == 0) {
@@ -2041,6 +2044,28 @@ static int agree_tau_cap_rccl(wt_handle *h, float tau)
     return WT_OK;
 }
 
+// The trimmed unit lists used to be cut the first time a pass needed them — 0.3 ms of planning on the host, a device allocation and a stream
+// synchronisation in the middle of the stepping loop, fifteen times per cycle at halo 61 and again for every residue a call's step count leaves behind
+// (a locally linked 8-slab group: 194 us per step over the first 610 steps, 119 once every list existed).  They are cut HERE now, all halo - 3 of them,
+// before the first launch of the first stepping call on a plan (0.3 ms each; trim_plan_for stays lazy for whoever calls it first).
+static int prebuild_trim_plans(wt_handle *h)
+{
+    if (h->trim_prebuilt || !(h->nranks > 1 && h->trim && h->fuse_ready && h->march_depth >= 3)) return WT_OK;
+    const int v_full = h->halo - (h->march_depth - 1);
+    for (int v_after = 0; v_after < v_full; v_after++) {
+        const MarchUnit *tu = nullptr;
+        int tn = 0;
+        WT_TRY(trim_plan_for(h, v_after, &tu, &tn));
+    }
+    if (h->refresh_mode == 2) {
+        wt_handle::RenewPlan *rp = nullptr;
+        const int k = fuse_pick(eff_depth(h), h->halo);
+        if (k > 0) WT_TRY(renew_plan_for(h, k, &rp));
+    }
+    h->trim_prebuilt = true;
+    return WT_OK;
+}
+
 // What a stepping call does before its first launch: the pass cap of this tau, the cross-rank checks that are due, the measured cut of a new plan.
 // (wt_step_timed runs it BEFORE its first event: the 13 trial passes of a new plan are not step time — ADVICE r3.)
 static int prepare_steps(wt_handle *h, int nsteps, double tau, double u0)
@@ -2051,6 +2076,7 @@ static int prepare_steps(wt_handle *h, int nsteps, double tau, double u0)
         WT_TRY(agree_tau_cap_rccl(h, (float)tau));
     }
     if (tune_due(h, nsteps)) WT_TRY(tune_fuse_plan(h, tau, u0));
+    WT_TRY(prebuild_trim_plans(h));
     return WT_OK;
 }
 
@@ -2295,6 +2321,7 @@ static int group_prepare(wt_handle **hs, int n, int nsteps, double tau, double u
     for (int r = 0; r < n; r++) {
         HIP_TRY(hipSetDevice(hs[r]->device));
         if (tune_due(hs[r], nsteps)) WT_TRY(tune_fuse_plan(hs[r], tau, u0));
+        WT_TRY(prebuild_trim_plans(hs[r]));
     }
     return WT_OK;
 }

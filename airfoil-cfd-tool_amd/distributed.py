@@ -31,7 +31,8 @@ def slab_bounds(nx: int, nranks: int, edges: Optional[List[int]] = None) -> List
     return [(edges[r], edges[r + 1] - edges[r]) for r in range(nranks)]
 
 
-DEFAULT_HALO = 29       # ghost columns per interior side: one refresh step + seven four-step passes between two exchanges (profiles/r04_g_trim_ab.txt)
+DEFAULT_HALO = 61       # ghost columns per interior side: one refresh step + fifteen four-step passes between two exchanges.  29 until round 5: with the
+                        # slabs on overlapping windows the measured AND the exchange-priced cost fall with the depth up to 61-77 (profiles/r05_z_halo_deep.txt)
 
 
 def default_halo(bounds: List[Tuple[int, int]], halo: Optional[int] = None) -> int:
@@ -364,7 +365,7 @@ class _LocalSlabEngine:
 
 class LocalSlabWindTunnel(WindTunnel):
     """:class:`WindTunnel` over several GPUs driven by ONE process (no torch.distributed, no RCCL):
-    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=29, nx=8192, ny=4096)``."""
+    ``LocalSlabWindTunnel(coords, devices=[0, 1, 2, 3], halo=61, nx=8192, ny=4096)``."""
 
     def __init__(self, coords=None, name: str = "", *, devices=(0,), halo: Optional[int] = None, edges=None, **kwargs):
         self.devices = [int(d) for d in devices]

@@ -92,11 +92,12 @@ def parse_args():
     ap.add_argument("--u0", type=float, default=0.06)
     ap.add_argument("--tau", type=float, default=None)
     ap.add_argument("--re", type=float, default=None, help="Reynolds number: tau = 0.5 + 3 U0 (NX / 1.84) / Re (SURVEY 8b) in place of --tau")
-    ap.add_argument("--halo", type=int, default=29,
-                    help="ghost columns per interior slab side (exchange every `halo` steps; 29 = one single refresh step + seven four-step passes.  With "
-                         "the ghost columns TRIMMED pass by pass (option trim_ghosts, round 4) a deeper halo costs little redundant work and halves the "
-                         "refresh steps: a locally linked 8-slab group runs 160 us per step at 17 untrimmed, 156 trimmed, 143 at 29, 139 at 41-49, "
-                         "profiles/r04_g_trim_ab.txt; the exchange grows with it, so not deeper than 29 by default)")
+    ap.add_argument("--halo", type=int, default=61,
+                    help="ghost columns per interior slab side (exchange every `halo` steps; 61 = one single refresh step + fifteen four-step passes.  With "
+                         "the ghost columns TRIMMED pass by pass (option trim_ghosts, round 4) a deeper halo costs little redundant work and spares refresh "
+                         "steps; the exchange grows with it.  Real slabs of the 8-way split of 4096^2 on overlapping windows, slowest slab measured / with the "
+                         "modelled exchange: 17.5 / 18.1 us per step at 29, 16.4 / 17.5 at 45, 16.0 / 17.3 at 61, 15.7 / 17.1 at 77 "
+                         "(profiles/r05_t_slab_costs_cfg2_overlap.txt, r05_z_halo_deep.txt)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="steps of the NumPy CPU baseline (0 = skip)")
     ap.add_argument("--fuse", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="two steps per pass over the lattice (csrc/step_march.hpp; fp32; bit-identical): -1 library "

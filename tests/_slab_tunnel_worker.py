@@ -24,7 +24,7 @@ def main():
     nx, ny, dtype = 1536, 768, sys.argv[1] if len(sys.argv) > 1 else "float32"
     kw = dict(shape="naca4412", nx=nx, ny=ny, aoa_deg=9.0, dtype=dtype)
     wt = pkg.SlabWindTunnel(device=0, **kw)                       # default halo (29, clamped to the narrowest slab), equal widths
-    assert wt.halo == min(29, nx // world) and wt.engine.get_option("comm_ranks") == world
+    assert wt.halo == min(pkg.distributed.DEFAULT_HALO, nx // world) and wt.engine.get_option("comm_ranks") == world
     frames = 9
     for _ in range(frames):
         wt.frame()

@@ -84,11 +84,11 @@ def test_traffic_and_valu_fraction_come_from_the_pass_kernels(bench):
 
 
 def test_default_halo_is_clamped_to_the_narrowest_slab():
-    """the hosts' default ghost depth (29 since round 4) must not exceed what the narrowest slab owns (wt_create_slab refuses that)."""
+    """the hosts' default ghost depth (29 in round 4, 61 since round 5) must not exceed what the narrowest slab owns (wt_create_slab refuses that)."""
     sys.path.insert(0, ROOT)
     from airfoil_cfd_tool_amd.distributed import DEFAULT_HALO, default_halo, slab_bounds
-    assert DEFAULT_HALO == 29
-    assert default_halo(slab_bounds(4096, 8)) == 29
+    assert DEFAULT_HALO == 61
+    assert default_halo(slab_bounds(4096, 8)) == 61
     assert default_halo(slab_bounds(128, 8)) == 16                      # 8 slabs of 16 columns: the default used to fail here
     assert default_halo(slab_bounds(100, 8)) == 12
     assert default_halo(slab_bounds(4096, 3, [0, 10, 2000, 4096])) == 10

@@ -45,7 +45,8 @@ def test_bench_two_ranks_end_to_end_over_the_stand_in_transport(stub):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank): slabs cut by measured cost, the library's
     communicator, warm-up, timed steps, the JSON line with the first-contact report of every rank."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29741",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "2048", "--ny", "1024", "--steps", "87", "--warmup", "29", "--cpu-steps", "0", "--balance", "1"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "2048", "--ny", "1024", "--steps", "87", "--warmup", "29", "--cpu-steps", "0", "--balance", "1",
+           "--halo", "29"]
     r = subprocess.run(cmd, env=_env(stub, WT_BENCH_FORCE_DEVICE="0", WT_BENCH_TORCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -64,7 +65,7 @@ def test_bench_two_ranks_without_a_launcher_over_the_stand_in_transport(stub):
     env = {k: v for k, v in _env(stub, WT_BENCH_FORCE_DEVICE="0", WT_BENCH_TORCH_BACKEND="gloo").items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "WT_BENCH_SELF_LAUNCHED")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "2048", "--ny", "1024", "--steps", "58", "--warmup", "29", "--cpu-steps", "0",
-           "--balance", "0"]
+           "--balance", "0", "--halo", "29"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "starting 2 ranks as a child job" in r.stderr

@@ -33,10 +33,10 @@ bench)
   for c in 0 1 3 4; do python3 bench.py --config $c --cpu-steps 3 > $out/bench_cfg$c.json 2> /dev/null; done
   echo "bench lines done";;
 slabs)
-  python3 bench.py --local-slabs 8 --steps 580 --warmup 58 > $out/bench_local_slabs8.json 2> /dev/null
+  python3 bench.py --local-slabs 8 --steps 610 --warmup 61 > $out/bench_local_slabs8.json 2> /dev/null
   g++ -O2 -std=c++17 -fPIC -shared -o /tmp/librccl_stub.so $R/tests/_rccl_stub/rccl_stub.cpp -ldl -lrt -lpthread && \
     LD_PRELOAD=/tmp/librccl_stub.so WT_BENCH_FORCE_DEVICE=0 WT_BENCH_TORCH_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0 \
-    timeout -k 10 500 python3 bench.py --gpus 4 --cpu-steps 0 --steps 116 --warmup 58 > $out/bench_4ranks_stub.json 2> $out/bench_4ranks_stub.err
+    timeout -k 10 500 python3 bench.py --gpus 4 --cpu-steps 0 --steps 122 --warmup 61 > $out/bench_4ranks_stub.json 2> $out/bench_4ranks_stub.err
   echo "slab lines done";;
 esac
 done
