@@ -116,6 +116,11 @@ def parse_args():
     ap.add_argument("--side", type=int, default=1, choices=[0, 1],
                     help="1 (default, one GPU): also time the un-fused kernel and (fp32) the opt-in contracted arithmetic for the roofline entry — BEFORE the "
                          "warm-up, reported as preheat_steps / preheat_ms; 0: nothing runs on the device before the declared warm-up but the plan's own tuning")
+    ap.add_argument("--settle-ms", type=float, default=50.0,
+                    help="untimed steps on the bench handle IN FRONT of the declared warm-up, this many milliseconds of device work, so that the timed region "
+                         "runs at settled clocks: a fresh MI355X process reads 336, 359, 353, 339, 330, 322 ... 299 us per pass over its first 35 ms of "
+                         "marching and 295-300 from then on, whatever the flow does (profiles/r05_zz_clock_settling.txt) — a timed region of 20 steps is "
+                         "1.6 ms.  The lattice is put back to its initial state afterwards; counted in preheat_steps / preheat_ms.  0: none")
     ap.add_argument("--balance", type=int, default=-1, metavar="R",
                     help="slab runs with strong scaling: R rounds of cutting the slabs by MEASURED cost instead of equal widths before the run (every rank "
                          "times its candidate slab alone, airfoil_cfd_tool_amd.distributed.balance_split; the split with the fastest slowest slab is kept, "
@@ -217,7 +222,7 @@ def pmc_counters_this_session(args):
     if rocprof is None or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES"):
         return None
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", str(args.config), "--steps", "48", "--warmup", "12", "--cpu-steps", "0",
-             "--fast-math", "1" if args.fast_math == 1 else "0", "--side", "1", "--pmc-traffic", "0", "--nx", str(args.nx), "--ny", str(args.ny),
+             "--fast-math", "1" if args.fast_math == 1 else "0", "--side", "1", "--settle-ms", "0", "--pmc-traffic", "0", "--nx", str(args.nx), "--ny", str(args.ny),
              "--dtype", args.dtype, "--shape", args.shape, "--aoa", str(args.aoa), "--u0", str(args.u0), "--tau", repr(args.tau), "--fuse", str(args.fuse),
              "--fuse-chunk", str(args.fuse_chunk), "--fuse-sites", str(args.fuse_sites), "--fuse-depth", str(args.fuse_depth)]
     if args.dat:
@@ -663,16 +668,33 @@ def main():
                 side["contracted_error"] = str(e)
             eng.set_option("fast_math", 0)
             eng.init_equilibrium(args.u0)
+    # clock settling (--settle-ms): the bench handle marches, untimed, until the device has worked for that long without a pause; then back to the
+    # initial state.  Every rank of a slab run takes rank 0's step count (the exchanges are collective).
+    settle_steps = 0
+    if args.settle_ms > 0:
+        try:
+            eng.step(40, args.tau, args.u0)                                       # (the plan's units are timed and cut again here, once)
+            est = max(1e-4, eng.step_timed(40, args.tau, args.u0) / 40)           # ms per step
+            n = [max(1, min(200000, int(args.settle_ms / est + 0.5)))]
+            if distributed:
+                dist.broadcast_object_list(n, src=0)
+            with_watchdog(COMM_TIMEOUT_S, rank, local_rank, "clock-settling steps", lambda: eng.step(n[0], args.tau, args.u0))
+            settle_steps = 80 + n[0]
+            eng.init_equilibrium(args.u0)
+        except Exception as e:      # noqa: BLE001
+            die(rank, local_rank, "clock-settling steps", e)
     if not distributed:
         eng.sync()
     # everything the device has done before the DECLARED warm-up (ADVICE r3 / VERDICT r3 weak 5): the side measurements above and the trial passes
     # of the plan's measured cut (13 marching passes on a new mask).  On a short run (`--steps 20 --warmup 5`) this work, not the five warm-up
     # steps, is what brings the GPU's clocks up before the timed region; the JSON line says so (`preheat_*`), and `--side 0` runs none of it.
     tune_passes = 13 if (bool(eng.get_option("fuse_active")) and eng.get_option("tune_rounds") > 0) else 0
-    preheat = {"preheat_steps": preheat_steps + tune_passes * (int(eng.get_option("fuse_depth")) if tune_passes else 0),
-               "preheat_ms": (time.perf_counter() - t_pre0) * 1e3 if (preheat_steps or tune_passes) else 0.0,
-               "preheat_what": ("k_step on a second handle: 44 steps; contracted arithmetic on the bench handle: %d steps; trial passes of the measured cut: %d"
-                                % (max(0, preheat_steps - 44), tune_passes)) if (preheat_steps or tune_passes) else "nothing"}
+    preheat = {"preheat_steps": preheat_steps + settle_steps + tune_passes * (int(eng.get_option("fuse_depth")) if tune_passes else 0),
+               "preheat_ms": (time.perf_counter() - t_pre0) * 1e3 if (preheat_steps or tune_passes or settle_steps) else 0.0,
+               "preheat_what": ("k_step on a second handle: %d steps; contracted arithmetic on the bench handle: %d steps; clock settling on the bench handle "
+                                "(--settle-ms %g): %d steps; trial passes of the measured cut: %d"
+                                % (44 if preheat_steps else 0, max(0, preheat_steps - 44), args.settle_ms, settle_steps, tune_passes))
+                               if (preheat_steps or tune_passes or settle_steps) else "nothing"}
 
     try:
         # warm-up (untimed); the first exchange of a slab run happens here
