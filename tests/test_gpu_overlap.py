@@ -72,11 +72,11 @@ def test_overlap_is_automatic_for_slabs_only_and_never_for_fp64_or_fast_math(pkg
             s.close()
 
 
-@pytest.mark.parametrize("overlap", [0, 1])
-def test_slab_group_equals_single_lattice_on_either_window_layout(pkg, overlap):
-    """Three local slabs of a tunnel with the body across two of them, through refresh steps and trimmed ghost passes, on overlapping windows (the
-    automatic choice for slabs) and on windows that tile the column (the layout of whole lattices, forced): owned columns bit-identical to the
-    single lattice."""
+@pytest.mark.parametrize("overlap,refresh", [(0, 0), (1, 0), (0, 2), (1, 2), (0, 1), (1, 1)])
+def test_slab_group_equals_single_lattice_on_either_window_layout(pkg, overlap, refresh):
+    """Three local slabs of a tunnel with the body across two of them, through ghost renewals of every kind (refresh 0 / 1 / 2) and trimmed ghost
+    passes, on overlapping windows (the automatic choice for slabs) and on windows that tile the column (the layout of whole lattices, forced): owned
+    columns bit-identical to the single lattice."""
     nx, ny, nsteps = 900, 744, 47
     mask = pkg.geometry.build_geometry(nx, ny, 8.0, None, "naca4412").mask
     ref_f, ref_m, _ = _run(pkg, nx, ny, mask, nsteps, {"fuse_steps": 0})
@@ -86,6 +86,7 @@ def test_slab_group_equals_single_lattice_on_either_window_layout(pkg, overlap):
         for s in es:
             s.set_option("fuse_steps", 2)
             s.set_option("window_overlap", overlap)
+            s.set_option("refresh", refresh)
             s.set_mask(mask)
             s.init_equilibrium(0.06)
         for n in (30, 17):
