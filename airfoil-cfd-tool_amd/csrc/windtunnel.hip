@@ -650,6 +650,19 @@ static int upload_units(wt_handle *h, const MarchPlan &plan_in)
     return WT_OK;
 }
 
+// Overlapping windows (k_march3, step_chain.hpp: four margin rows on either side in place of the halo lines): 128 / 120 of the arithmetic and loads /
+// stores that straddle lines for no halo kernel — 10 of the 58 us of a pass on a slab of an 8-way split of 4096^2, 21 of 307 on the whole lattice.
+// Automatic: the fp32 slabs of a split (and stand-alone handles that plan like one, plan_columns), and whole lattices up to 7.5 M sites — measured
+// (profiles/r05_zy_overlap_sizes.txt, us per step tiling / overlapping): 1024x512 11.8 / 9.3, 2048x1024 19.5 / 14.5, 2048^2 24.8 / 23.2, 3584x2048
+// 37.2 / 35.4, but 4096x2048 42.5 / 46.9, 3072^2 45.8 / 51.2, 4096^2 77 / 90-97: the large ones are half bound by their line traffic.  fp64 windows
+// would keep 56 rows of 64; the contracted kernels (fast_math) know no such windows.
+static bool want_overlap(const wt_handle *h)
+{
+    if (h->dtype != WT_F32 || h->fast_math) return false;
+    if (h->win_overlap >= 0) return h->win_overlap > 0;
+    return h->nranks > 1 || h->plan_columns > 0 || (long)h->g.nxl * h->g.ny <= 7500000L;
+}
+
 // Classes, bounce codes and the unit lists of the current mask for windows of 64 * sites rows.  Everything but the
 // cuts of the column ranges runs on the device; the host reads nwin x (nxl+2) class bytes back.
 static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
@@ -657,10 +670,7 @@ static int build_fuse_plan(wt_handle *h, int sites, long target, int depth)
     const Geom &g = h->g;
     const int win = 64 * sites;
     const size_t eb = h->dtype == WT_F32 ? 4 : 8;
-    // Overlapping windows (k_march3, step_chain.hpp: four margin rows on either side in place of the halo lines): 128 / 120 of the arithmetic for no
-    // halo kernel — 10 of the 58 us of a pass on a slab of an 8-way split of 4096^2, 21 of 307 on the whole lattice.  Automatic: the fp32 slabs of a
-    // split (and stand-alone handles that plan like one, plan_columns); fp64 windows would keep 56 rows of 64.
-    h->ovl = depth >= 3 && h->dtype == WT_F32 && !h->fast_math && (h->win_overlap > 0 || (h->win_overlap < 0 && (h->nranks > 1 || h->plan_columns > 0)));
+    h->ovl = depth >= 3 && want_overlap(h);
     const int wstride = h->ovl ? win - 8 : win, woff = h->ovl ? -4 : 0;
     const int nwin = march_nwin(g.ny, wstride);
     const size_t wbytes = (size_t)nwin * (g.nxl + 2), cbytes = (size_t)(g.nxl + 2) * g.pitch;
@@ -789,7 +799,9 @@ static int rebuild_fuse_plan(wt_handle *h)
         const bool f32 = h->dtype == WT_F32;
         const long cpu = tiles3 / slots;
         static const long min4_env = exp_env("WT_DEPTH4_MIN") ? atol(exp_env("WT_DEPTH4_MIN")) : 0;      // experiments
-        const long min4 = min4_env > 0 ? min4_env : ((h->nranks > 1 || h->plan_columns > 0) ? 5 : 8);
+        // (whole lattices on overlapping windows — want_overlap: the small ones — pay no halo kernel per pass: four steps from four columns per unit,
+        //  1536x768 11.8 against 12.6 us per step, 2048x1024 14.5 against 16.8; 1024x512, two per unit, stays at three: 9.2 against 10.0)
+        const long min4 = min4_env > 0 ? min4_env : ((h->nranks > 1 || h->plan_columns > 0) ? 5 : (want_overlap(h) ? 4 : 8));
         static const long min3 = exp_env("WT_DEPTH3_MIN") ? atol(exp_env("WT_DEPTH3_MIN")) : 1;
         const bool force = h->fuse_force || h->fuse_depth >= 2;
         if (!force && h->fuse_chunk <= 0 && cpu < (f32 ? min3 : 4)) return WT_OK;

@@ -772,6 +772,9 @@ def main():
         main_kernel = "wt::k_march3 (THREE steps per pass, body / inlet / outlet inside; + wt::k_halo3 per pass)"
     elif fused:
         main_kernel = "wt::k_march (TWO steps per pass, body / inlet / outlet inside; + wt::k_halo_from_seams per pass)"
+    if fused and steps_per_launch >= 3 and int(eng.get_option("window_overlap")) == 1:
+        # overlapping windows (slabs, whole lattices of up to 7.5 M sites): the pass is the marching kernel alone
+        main_kernel = main_kernel.split(";")[0] + "; OVERLAPPING windows: 128 rows of which the middle 120 are owned, no halo kernel)"
     traffic = None if distributed else (select_traffic(session_counters, fused, steps_per_launch) or
                                         measured_traffic(key + (("_march4" if steps_per_launch == 4 else "_march3" if steps_per_launch == 3 else "_march") if fused else "")))
     r = roofline_entry(main_kernel, bpl * sites_per_launch * steps_per_launch, launch_ms, traffic)

@@ -1,7 +1,7 @@
 """GPU: the marching kernels on OVERLAPPING windows (option window_overlap; csrc/step_chain.hpp k_march3: windows of 128 rows that own the 120 in the
 middle and carry four margin rows on either side instead of reading halo lines) — the same bits as single steps (STEP_FS, html:283-360, once per
 step) on lattices whose height is and is not a multiple of the window stride, with the body in the first window, in the last, across a seam; the
-automatic choice (slabs of a split: on; whole lattices: off); the options that exclude it."""
+automatic choice (slabs of a split and whole lattices of up to 7.5 M sites: on; larger whole lattices: off); the options that exclude it."""
 import numpy as np
 import pytest
 
@@ -35,17 +35,16 @@ def test_overlapping_windows_equal_single_steps(pkg, nx, ny, shape, aoa, nsteps,
         assert bits_equal(a, b)
 
 
-def test_overlap_is_automatic_for_slabs_only_and_never_for_fp64_or_fast_math(pkg):
+def test_overlap_is_automatic_for_slabs_and_small_lattices_and_never_for_fp64_or_fast_math(pkg):
     nx, ny = 640, 512
     mask = pkg.geometry.build_geometry(nx, ny, 5.0, None, "naca2412").mask
-    with pkg.Engine(nx, ny) as e:                      # a whole lattice: windows that tile the column
+    with pkg.Engine(nx, ny) as e:                      # a whole lattice of up to 7.5 M sites: overlapping (cache-resident, not bound by line traffic)
         e.set_option("fuse_steps", 2)
         e.set_mask(mask)
-        assert e.get_option("fuse_active") == 1.0 and e.get_option("window_overlap") == 0.0
-        e.set_option("plan_columns", 320)              # ... planned like a slab of a split: overlapping
-        assert e.get_option("window_overlap") == 1.0
-        e.set_option("plan_columns", 0)
-        e.set_option("window_overlap", 1)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("window_overlap") == 1.0
+        e.set_option("window_overlap", 0)
+        assert e.get_option("window_overlap") == 0.0
+        e.set_option("window_overlap", -1)
         assert e.get_option("window_overlap") == 1.0
         e.set_option("fast_math", 1)                   # the contracted kernels know no overlapping windows: the plan is cut again
         assert e.get_option("window_overlap") == 0.0
@@ -55,6 +54,13 @@ def test_overlap_is_automatic_for_slabs_only_and_never_for_fp64_or_fast_math(pkg
         assert e.get_option("window_overlap") == 1.0
         with pytest.raises(pkg.WTError):
             e.set_option("window_overlap", 2)
+    big = np.zeros((2048, 4096), np.uint8)
+    big[1000:1040, 1000:1400] = 1
+    with pkg.Engine(4096, 2048) as e:                  # a large whole lattice: windows that tile the column ...
+        e.set_mask(big)
+        assert e.get_option("fuse_active") == 1.0 and e.get_option("window_overlap") == 0.0
+        e.set_option("plan_columns", 541)              # ... unless it plans like a slab of a split
+        assert e.get_option("window_overlap") == 1.0
     with pkg.Engine(nx, ny, dtype="float64") as e:
         e.set_option("fuse_steps", 2)
         e.set_option("window_overlap", 1)
