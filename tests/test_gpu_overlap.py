@@ -10,7 +10,7 @@ from conftest import bits_equal
 pytestmark = pytest.mark.gpu
 
 CASES = [(320, 256, "naca0012", 4.0, 37), (768, 1000, "naca4412", 12.0, 29), (512, 120, "naca0012", 0.0, 23), (544, 1366, "naca6409", 10.0, 31),
-         (400, 242, "naca2412", -6.0, 26)]
+         (400, 242, "naca2412", -6.0, 26), (4096, 16, "naca0012", 2.0, 19), (3000, 30, "naca2412", 5.0, 21), (2200, 122, "naca4412", 9.0, 17)]
 
 
 def _run(pkg, nx, ny, mask, nsteps, opts, dtype="float32", tau=0.58):
