@@ -635,4 +635,22 @@ static inline MarchPlan build_chain_plan_timed(const uint8_t *wcls, const Geom &
     return pl;
 }
 
+// Workgroup k of a launch runs on XCD k mod 8 (each with its own L2).  The planners list the workgroups chunk-major — the windows of one column range
+// next to one another —, so dealt out round-robin two windows that are vertical neighbours never share an L2.  For OVERLAPPING windows that matters:
+// neighbours read one 128-byte line in common per population and column and write the two halves of another.  Here the list is cut into eight
+// contiguous runs and run x is dealt to the positions x, x + 8, x + 16 ...: every XCD gets a stretch of column ranges with all their windows.
+// (padded with empty workgroups to a multiple of eight; the reversed launch order of every other pass keeps the runs together)
+static inline void xcd_order(std::vector<MarchUnit> &units)
+{
+    const size_t nb = (units.size() + 3) / 4;
+    if (nb < 16) return;
+    const size_t L = (nb + 7) / 8;
+    std::vector<MarchUnit> out(L * 8 * 4, MarchUnit{0, 0, units.empty() ? 0 : units[0].w, 0});
+    for (size_t b = 0; b < nb; b++) {
+        const size_t x = b / L, q = b % L, i = 8 * q + x;
+        for (size_t k = 0; k < 4 && 4 * b + k < units.size(); k++) out[4 * i + k] = units[4 * b + k];
+    }
+    units.swap(out);
+}
+
 }  // namespace wt

@@ -587,24 +587,7 @@ static void cut_units(wt_handle *h, const float *colw, MarchPlan *out, const Mar
     *out = std::move(pl);
 }
 
-// Workgroup k of a launch runs on XCD k mod 8 (each with its own L2).  The planners list the workgroups chunk-major — the windows of one column range
-// next to one another —, so dealt out round-robin two windows that are vertical neighbours never share an L2.  For OVERLAPPING windows that matters:
-// neighbours read one 128-byte line in common per population and column and write the two halves of another.  Here the list is cut into eight
-// contiguous runs and run x is dealt to the positions x, x + 8, x + 16 ...: every XCD gets a stretch of column ranges with all their windows.
-// (padded with empty workgroups to a multiple of eight; the reversed launch order of every other pass keeps the runs together)
-static void xcd_order(std::vector<MarchUnit> &units)
-{
-    const size_t nb = (units.size() + 3) / 4;
-    if (nb < 16) return;
-    const size_t L = (nb + 7) / 8;
-    std::vector<MarchUnit> out(L * 8 * 4, MarchUnit{0, 0, units.empty() ? 0 : units[0].w, 0});
-    for (size_t b = 0; b < nb; b++) {
-        const size_t x = b / L, q = b % L, i = 8 * q + x;
-        for (size_t k = 0; k < 4 && 4 * b + k < units.size(); k++) out[4 * i + k] = units[4 * b + k];
-    }
-    units.swap(out);
-}
-// On for plans with overlapping windows, i.e. slabs (profiles/r05_s_xcd_order.txt: stand-alone slabs of the 8-way split of 4096^2 12.4-12.6 against
+// xcd_order (step_chain.hpp) is on for plans with overlapping windows — slabs and small whole lattices — (profiles/r05_s_xcd_order.txt: stand-alone slabs of the 8-way split of 4096^2 12.4-12.6 against
 // 13.0-13.8 us per step plain, 13.9-14.7 against 14.7-14.9 over the body; windows that tile the column gain 2-4 % on a slab and lose on the whole lattice).
 static bool xcd_order_on(const wt_handle *h)
 {

@@ -141,9 +141,39 @@ static int check_sanitize(int depth, int corruption, unsigned seed)
     return bad;
 }
 
+// xcd_order (step_chain.hpp): the workgroups (aligned groups of four units) of a plan dealt to the XCDs in contiguous runs — a permutation of the
+// groups, padded with empty groups to a multiple of eight, every group intact, group b of the chunk-major list on XCD b / ceil(groups / 8)
+static int check_xcd_order(int ngroups, unsigned seed)
+{
+    std::mt19937 rng(seed);
+    std::vector<MarchUnit> u;
+    for (int b = 0; b < ngroups; b++)
+        for (int k = 0; k < 4; k++) u.push_back(MarchUnit{(int)(1 + b * 40 + k * 10), (int)(1 + b * 40 + k * 10 + 10), (int)(rng() % 35), (int)(rng() % 16)});
+    const std::vector<MarchUnit> in = u;
+    xcd_order(u);
+    int bad = 0;
+    if (ngroups < 16) { bad += u.size() != in.size(); for (size_t i = 0; i < in.size() && !bad; i++) bad += u[i].ia != in[i].ia; }
+    else {
+        const size_t L = ((size_t)ngroups + 7) / 8;
+        bad += u.size() != L * 32;
+        std::vector<int> seen((size_t)ngroups, 0);
+        for (size_t i = 0; i + 3 < u.size(); i += 4) {
+            if (u[i].ib <= u[i].ia) { for (int k = 0; k < 4; k++) bad += u[i + k].ib > u[i + k].ia; continue; }       // an empty group is empty throughout
+            const int b = (u[i].ia - 1) / 40;
+            for (int k = 0; k < 4; k++) bad += u[i + k].ia != in[(size_t)4 * b + k].ia || u[i + k].w != in[(size_t)4 * b + k].w || u[i + k].flags != in[(size_t)4 * b + k].flags;
+            seen[(size_t)b]++;
+            bad += (i / 4) % 8 != (size_t)b / L;                          // workgroup position mod 8 = the XCD = the run the group belongs to
+        }
+        for (int b = 0; b < ngroups; b++) bad += seen[(size_t)b] != 1;
+    }
+    printf("xcd_order, %4d groups: %s\n", ngroups, bad ? "FAIL" : "ok");
+    return bad;
+}
+
 int main()
 {
     int bad = 0;
+    for (int n : {3, 15, 16, 17, 255, 256, 512, 513, 519}) bad += check_xcd_order(n, 7u + (unsigned)n);
     for (int depth : {3, 4})
         for (int c = 0; c < 6; c++) bad += check_sanitize(depth, c, 100u + (unsigned)(10 * depth + c));
     for (int depth : {2, 3, 4}) {
