@@ -635,15 +635,16 @@ static int upload_units(wt_handle *h, const MarchPlan &plan_in)
 
 // Overlapping windows (k_march3, step_chain.hpp: four margin rows on either side in place of the halo lines): 128 / 120 of the arithmetic and loads /
 // stores that straddle lines for no halo kernel — 10 of the 58 us of a pass on a slab of an 8-way split of 4096^2, 21 of 307 on the whole lattice.
-// Automatic: the fp32 slabs of a split (and stand-alone handles that plan like one, plan_columns), and whole lattices up to 7.5 M sites — measured
+// Automatic: fp32 lattices — whole ones and the slabs of a split alike, by their LOCAL size — of up to 7.5 M sites.  Measured
 // (profiles/r05_zy_overlap_sizes.txt, us per step tiling / overlapping): 1024x512 11.8 / 9.3, 2048x1024 19.5 / 14.5, 2048^2 24.8 / 23.2, 3584x2048
-// 37.2 / 35.4, but 4096x2048 42.5 / 46.9, 3072^2 45.8 / 51.2, 4096^2 77 / 90-97: the large ones are half bound by their line traffic.  fp64 windows
-// would keep 56 rows of 64; the contracted kernels (fast_math) know no such windows.
+// 37.2 / 35.4, but 4096x2048 42.5 / 46.9, 3072^2 45.8 / 51.2, 4096^2 77 / 90-97: the large ones are half bound by their line traffic; slabs of 4096
+// rows: 600 columns (8-way split of 4096^2) 19.9 / 17.5, 1150 columns (4-way) 28.4 / 25.4, but 2110 columns (2-way) 44.1 / 46.4-48.3, and the
+// 2170-column slabs of 16384x4096 47.6-47.9 / 47.4-50.5.  fp64 windows would keep 56 rows of 64; the contracted kernels (fast_math) know no such windows.
 static bool want_overlap(const wt_handle *h)
 {
     if (h->dtype != WT_F32 || h->fast_math) return false;
     if (h->win_overlap >= 0) return h->win_overlap > 0;
-    return h->nranks > 1 || h->plan_columns > 0 || (long)h->g.nxl * h->g.ny <= 7500000L;
+    return (long)h->g.nxl * h->g.ny <= 7500000L;
 }
 
 // Classes, bounce codes and the unit lists of the current mask for windows of 64 * sites rows.  Everything but the

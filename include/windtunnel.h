@@ -147,11 +147,12 @@ WT_API const char *wt_version(void);
  *       from a seam buffer the pass before wrote.  1: OVERLAPPING windows — a window owns the 120 rows in its middle and carries four margin rows
  *       on either side, which lose one row of validity per level and are never stored: no halo lines, no halo kernel, no seam buffer, 128 / 120
  *       of the arithmetic, loads and stores that straddle cache lines; the workgroups of such a plan are dealt to the XCDs in contiguous runs
- *       (vertical neighbours share an L2).  The same bits either way.  Automatic: the slabs of a split (and "plan_columns" stand-ins) overlap —
- *       the halo kernel is a fixed 10 of the 58 us of a slab's pass: slowest real slab of the 8-way split of 4096^2 19.9 -> 17.5 us per step
- *       (profiles/r05_t_slab_costs_cfg2_overlap.txt) —, and so do whole lattices of up to 7.5 M sites (1024x512: 11.8 -> 9.3 us per step,
- *       2048x1024: 19.5 -> 14.5, 3584x2048: 37.2 -> 35.4; profiles/r05_zy_overlap_sizes.txt); larger whole lattices tile (4096x2048: 42.5 against
- *       46.9, 4096^2: 77 against 90-97: half bound by their line traffic).  fp64 handles and "fast_math" always tile.  Rank-local: the steps per pass are chosen from the tiling windows' count either
+ *       (vertical neighbours share an L2).  The same bits either way.  Automatic: lattices — whole ones and the slabs of a split alike, by their
+ *       LOCAL size — of up to 7.5 M sites overlap: the halo kernel is a fixed 10 of the 58 us of a pass on a 600-column slab (slowest real slab of the
+ *       8-way split of 4096^2 19.9 -> 17.5 us per step, profiles/r05_t_slab_costs_cfg2_overlap.txt), and 1024x512 goes 11.8 -> 9.3 us per step,
+ *       2048x1024 19.5 -> 14.5, 3584x2048 37.2 -> 35.4 (profiles/r05_zy_overlap_sizes.txt); larger ones tile (4096x2048: 42.5 against 46.9, 4096^2:
+ *       77 against 90-97, a 2110-column slab of 4096 rows 44.1 against 46.4-48.3: half bound by their line traffic).  fp64 handles and "fast_math"
+ *       always tile.  Rank-local: the steps per pass are chosen from the tiling windows' count either
  *       way, so the sequence of passes does not depend on it.  wt_get_option reports the present plan's layout.
  *   "refresh" (default 0, slab handles): how the ghost columns are renewed.  0: by a SINGLE step (k_step) whose interior columns run beside the
  *       exchange, the two edge strips (the ghost columns + one owned column: a few microseconds) after it — the step runs at the un-fused rate

@@ -1,7 +1,7 @@
 """GPU: the marching kernels on OVERLAPPING windows (option window_overlap; csrc/step_chain.hpp k_march3: windows of 128 rows that own the 120 in the
 middle and carry four margin rows on either side instead of reading halo lines) — the same bits as single steps (STEP_FS, html:283-360, once per
 step) on lattices whose height is and is not a multiple of the window stride, with the body in the first window, in the last, across a seam; the
-automatic choice (slabs of a split and whole lattices of up to 7.5 M sites: on; larger whole lattices: off); the options that exclude it."""
+automatic choice (lattices — whole ones and slabs alike — of up to 7.5 M local sites: on; larger ones: off); the options that exclude it."""
 import numpy as np
 import pytest
 
@@ -56,10 +56,12 @@ def test_overlap_is_automatic_for_slabs_and_small_lattices_and_never_for_fp64_or
             e.set_option("window_overlap", 2)
     big = np.zeros((2048, 4096), np.uint8)
     big[1000:1040, 1000:1400] = 1
-    with pkg.Engine(4096, 2048) as e:                  # a large whole lattice: windows that tile the column ...
+    with pkg.Engine(4096, 2048) as e:                  # a large lattice (8.4 M sites): windows that tile the column, whatever it plans like
         e.set_mask(big)
         assert e.get_option("fuse_active") == 1.0 and e.get_option("window_overlap") == 0.0
-        e.set_option("plan_columns", 541)              # ... unless it plans like a slab of a split
+        e.set_option("plan_columns", 541)
+        assert e.get_option("window_overlap") == 0.0
+        e.set_option("window_overlap", 1)
         assert e.get_option("window_overlap") == 1.0
     with pkg.Engine(nx, ny, dtype="float64") as e:
         e.set_option("fuse_steps", 2)
@@ -72,7 +74,7 @@ def test_overlap_is_automatic_for_slabs_and_small_lattices_and_never_for_fp64_or
         for s in es:
             s.set_option("fuse_steps", 2)
             s.set_mask(mask)
-        assert all(s.get_option("fuse_active") == 1.0 and s.get_option("window_overlap") == 1.0 for s in es)
+        assert all(s.get_option("fuse_active") == 1.0 and s.get_option("window_overlap") == 1.0 for s in es)      # (by their local size, like whole lattices)
     finally:
         for s in es:
             s.close()

@@ -37,6 +37,8 @@ def priced(m, mode):
 
 for mode in modes:
     opts = {"refresh": mode}
+    if os.environ.get("WT_SLAB_OVERLAP"):                      # experiments: force the window layout of the slabs (0 tiling, 1 overlapping)
+        opts["window_overlap"] = int(os.environ["WT_SLAB_OVERLAP"])
     measure = lambda ed: [pkg.measure_slab_real(mask, ed, r, halo, options=opts) for r in range(P)]
     hist = []
     best, _ = pkg.balance_split(nx, P, max(2 * halo, 64), lambda ed: (hist.append((list(ed), measure(ed))) or [priced(m, mode)[0] for m in hist[-1][1]]), rounds)
