@@ -37,6 +37,8 @@ def priced(m, mode):
 
 for mode in modes:
     opts = {"refresh": mode}
+    if os.environ.get("WT_SLAB_TRIM"):                         # experiments: trimmed ghost marching on / off
+        opts["trim_ghosts"] = int(os.environ["WT_SLAB_TRIM"])
     if os.environ.get("WT_SLAB_OVERLAP"):                      # experiments: force the window layout of the slabs (0 tiling, 1 overlapping)
         opts["window_overlap"] = int(os.environ["WT_SLAB_OVERLAP"])
     measure = lambda ed: [pkg.measure_slab_real(mask, ed, r, halo, options=opts) for r in range(P)]
