@@ -71,7 +71,7 @@ def test_marching_loop_instruction_budget(isa_files):
         "_ZN2wt8k_march3IfLi2ELi4ELb0ELi17EEEvNS_11MarchParamsIT_EE": (1042, 814, 496, 90),
         "_ZN2wt8k_march3IfLi2ELi4ELb0ELi1EEEvNS_11MarchParamsIT_EE": (1078, 850, 532, 90),
         "_ZN2wt8k_march3IdLi1ELi4ELb0ELi1EEEvNS_11MarchParamsIT_EE": (1225, 1032, 0, 56),
-        # overlapping windows (FD bit 5; the slabs' kernel): no halo-line load, six data-parallel moves per stage instead of twelve, no seam rows — 985 / 785
+        # overlapping windows (FD bit 5; slabs and small whole lattices): no halo-line load, six data-parallel moves per stage instead of twelve, no seam rows — 985 / 785
         "_ZN2wt8k_march3IfLi2ELi4ELb0ELi49EEEvNS_11MarchParamsIT_EE": (996, 794, 496, 90),
     }
     for sym, (ex_max, valu_max, pk_max, mov_max) in budget.items():
